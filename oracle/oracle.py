@@ -1,0 +1,298 @@
+"""ctypes binding of the CPU oracle (oracle/amg_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libamg_oracle.so")
+
+SM_SPGS, SM_REF_JACOBI, SM_SOR, SM_TRUE_JACOBI, SM_MULTICOLOR = 0, 1, 2, 3, 4
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "amg_oracle.cpp")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+
+def _p32(a):
+    return None if a is None else a.ctypes.data_as(_i32p)
+
+
+def _p64(a):
+    return None if a is None else a.ctypes.data_as(_f64p)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_grid_spacing_h.restype = C.c_double
+        L.orc_grid_spacing_h.argtypes = [C.c_uint64]
+        L.orc_points_n_from_grid_spacing_h.restype = C.c_uint64
+        L.orc_points_n_from_grid_spacing_h.argtypes = [C.c_double]
+        L.orc_laplacian.restype = C.c_int64
+        L.orc_laplacian.argtypes = [C.c_int, C.c_uint64, _i32p, _i32p, _f64p]
+        L.orc_rhs.restype = None
+        L.orc_rhs.argtypes = [C.c_int, C.c_uint64, _f64p]
+        L.orc_n_H_from_n_h.restype = C.c_uint64
+        L.orc_n_H_from_n_h.argtypes = [C.c_uint64]
+        L.orc_make_P.restype = C.c_int64
+        L.orc_make_P.argtypes = [C.c_uint64, C.c_uint64, _i32p, _i32p, _f64p]
+        L.orc_transpose.restype = None
+        L.orc_transpose.argtypes = [C.c_int64, C.c_int64, _i32p, _i32p, _f64p,
+                                    _i32p, _i32p, _f64p]
+        L.orc_residual.restype = None
+        L.orc_residual.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, _f64p]
+        L.orc_spmv.restype = None
+        L.orc_spmv.argtypes = [C.c_int64, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
+        L.orc_rss.restype = C.c_double
+        L.orc_rss.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
+        L.orc_smooth.restype = C.c_uint64
+        L.orc_smooth.argtypes = [C.c_int, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p,
+                                 C.c_double, C.c_double, C.c_uint64, C.c_uint64,
+                                 _i32p, C.c_int32, C.POINTER(C.c_int)]
+        L.orc_spgs_sweep.restype = None
+        L.orc_spgs_sweep.argtypes = [C.c_int, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
+        L.orc_band_solve.restype = C.c_int64
+        L.orc_band_solve.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
+        L.orc_mg_create.restype = C.c_void_p
+        L.orc_mg_create.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_uint64]
+        L.orc_mg_destroy.restype = None
+        L.orc_mg_destroy.argtypes = [C.c_void_p]
+        L.orc_mg_set_smoother.restype = None
+        L.orc_mg_set_smoother.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_double]
+        L.orc_mg_set_colors.restype = None
+        L.orc_mg_set_colors.argtypes = [C.c_void_p, C.c_uint64, _i32p, C.c_int32]
+        L.orc_mg_n_dofs.restype = C.c_uint64
+        L.orc_mg_n_dofs.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_mg_level_nnz.restype = C.c_int64
+        L.orc_mg_level_nnz.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_mg_level_matrix.restype = None
+        L.orc_mg_level_matrix.argtypes = [C.c_void_p, C.c_uint64, _i32p, _i32p, _f64p]
+        L.orc_mg_transfer_nnz.restype = C.c_int64
+        L.orc_mg_transfer_nnz.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+        L.orc_mg_transfer.restype = None
+        L.orc_mg_transfer.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _i32p, _i32p, _f64p]
+        L.orc_mg_get_vec.restype = None
+        L.orc_mg_get_vec.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _f64p]
+        L.orc_mg_set_vec.restype = None
+        L.orc_mg_set_vec.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _f64p]
+        L.orc_mg_coarse_halfbw.restype = C.c_int64
+        L.orc_mg_coarse_halfbw.argtypes = [C.c_void_p]
+        L.orc_mg_vcycle.restype = None
+        L.orc_mg_vcycle.argtypes = [C.c_void_p]
+        L.orc_mg_rss.restype = C.c_double
+        L.orc_mg_rss.argtypes = [C.c_void_p]
+        L.orc_mg_solve.restype = C.c_uint64
+        L.orc_mg_solve.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint64,
+                                   C.POINTER(C.c_int), _f64p, _f64p, C.c_uint64]
+        L.orc_mg_time_vcycles.restype = C.c_double
+        L.orc_mg_time_vcycles.argtypes = [C.c_void_p, C.c_uint64]
+        _lib = L
+    return _lib
+
+
+class CSC:
+    """Column-major sparse matrix, int32 indices (Eigen::SparseMatrix<double>)."""
+
+    def __init__(self, rows, cols, colptr, rowind, val):
+        self.rows, self.cols = int(rows), int(cols)
+        self.colptr = np.ascontiguousarray(colptr, dtype=np.int32)
+        self.rowind = np.ascontiguousarray(rowind, dtype=np.int32)
+        self.val = np.ascontiguousarray(val, dtype=np.float64)
+
+    @property
+    def nnz(self):
+        return int(self.rowind.size)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csc_matrix((self.val, self.rowind, self.colptr),
+                             shape=(self.rows, self.cols))
+
+    def transpose(self):
+        tc = np.empty(self.rows + 1, np.int32)
+        tr = np.empty(self.nnz, np.int32)
+        tv = np.empty(self.nnz, np.float64)
+        lib().orc_transpose(self.rows, self.cols, _p32(self.colptr), _p32(self.rowind),
+                            _p64(self.val), _p32(tc), _p32(tr), _p64(tv))
+        return CSC(self.cols, self.rows, tc, tr, tv)
+
+
+def laplacian(n, dim=2):
+    """grid.hpp:88-98 (dim=2); dim=3 is the build-side 7-point analogue."""
+    N = n ** dim
+    nnz = lib().orc_laplacian(dim, n, None, None, None)
+    colptr = np.empty(N + 1, np.int32)
+    rowind = np.empty(nnz, np.int32)
+    val = np.empty(nnz, np.float64)
+    lib().orc_laplacian(dim, n, _p32(colptr), _p32(rowind), _p64(val))
+    return CSC(N, N, colptr, rowind, val)
+
+
+def rhs(n, dim=2):
+    """grid.hpp:108-140 with the default Gaussian forcing."""
+    b = np.empty(n ** dim, np.float64)
+    lib().orc_rhs(dim, n, _p64(b))
+    return b
+
+
+def grid_spacing_h(n):
+    return lib().orc_grid_spacing_h(n)
+
+
+def points_n_from_grid_spacing_h(h):
+    return int(lib().orc_points_n_from_grid_spacing_h(h))
+
+
+def n_H_from_n_h(n_h):
+    return int(lib().orc_n_H_from_n_h(n_h))
+
+
+def make_P(n_h, n_H):
+    nnz = lib().orc_make_P(n_h, n_H, None, None, None)
+    colptr = np.empty(n_H + 1, np.int32)
+    rowind = np.empty(nnz, np.int32)
+    val = np.empty(nnz, np.float64)
+    lib().orc_make_P(n_h, n_H, _p32(colptr), _p32(rowind), _p64(val))
+    return CSC(n_h, n_H, colptr, rowind, val)
+
+
+def residual(A, u, f):
+    r = np.empty(A.rows, np.float64)
+    lib().orc_residual(A.rows, _p32(A.colptr), _p32(A.rowind), _p64(A.val),
+                       _p64(np.ascontiguousarray(u)), _p64(np.ascontiguousarray(f)), _p64(r))
+    return r
+
+
+def spmv(M, v):
+    out = np.empty(M.rows, np.float64)
+    lib().orc_spmv(M.rows, M.cols, _p32(M.colptr), _p32(M.rowind), _p64(M.val),
+                   _p64(np.ascontiguousarray(v)), _p64(out))
+    return out
+
+
+def rss(A, u, b):
+    return lib().orc_rss(A.rows, _p32(A.colptr), _p32(A.rowind), _p64(A.val),
+                         _p64(np.ascontiguousarray(u)), _p64(np.ascontiguousarray(b)))
+
+
+def smooth(kind, A, u, b, n_iters=1, omega=1.0, tol=1e-9, every=0, color=None,
+           n_colors=0):
+    """Runs smoother `kind` in place on a copy of u; returns (u, iters, converged)."""
+    u = np.array(u, dtype=np.float64, copy=True)
+    conv = C.c_int(0)
+    col = None if color is None else np.ascontiguousarray(color, dtype=np.int32)
+    it = lib().orc_smooth(kind, A.rows, _p32(A.colptr), _p32(A.rowind), _p64(A.val),
+                          _p64(u), _p64(np.ascontiguousarray(b)), omega, tol, every,
+                          n_iters, _p32(col), n_colors, C.byref(conv))
+    return u, int(it), bool(conv.value)
+
+
+def spgs_sweep(direction, A, u, b):
+    u = np.array(u, dtype=np.float64, copy=True)
+    lib().orc_spgs_sweep(direction, A.rows, _p32(A.colptr), _p32(A.rowind),
+                         _p64(A.val), _p64(u), _p64(np.ascontiguousarray(b)))
+    return u
+
+
+def band_solve(A, f):
+    x = np.empty(A.rows, np.float64)
+    w = lib().orc_band_solve(A.rows, _p32(A.colptr), _p32(A.rowind), _p64(A.val),
+                             _p64(np.ascontiguousarray(f)), _p64(x))
+    return x, int(w)
+
+
+class Multigrid:
+    """Restatement of AMG::Multigrid<double> (multigrid.hpp) with
+    LinearInterpolator and a selectable smoother (default SparseGaussSeidel())."""
+
+    def __init__(self, A, b, n_levels, smoother=SM_SPGS, smoother_iters=1, omega=1.0):
+        self._h = lib().orc_mg_create(A.rows, _p32(A.colptr), _p32(A.rowind),
+                                      _p64(A.val), _p64(np.ascontiguousarray(b)), n_levels)
+        if not self._h:
+            raise ValueError("orc_mg_create failed")
+        self.n_levels = n_levels
+        lib().orc_mg_set_smoother(self._h, smoother, smoother_iters, omega)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_mg_destroy(self._h)
+            self._h = None
+
+    def set_colors(self, level, color, n_colors):
+        c = np.ascontiguousarray(color, dtype=np.int32)
+        lib().orc_mg_set_colors(self._h, level, _p32(c), n_colors)
+
+    def n_dofs(self, level):
+        return int(lib().orc_mg_n_dofs(self._h, level))
+
+    def level_matrix(self, level):
+        n = self.n_dofs(level)
+        nnz = lib().orc_mg_level_nnz(self._h, level)
+        colptr = np.empty(n + 1, np.int32)
+        rowind = np.empty(nnz, np.int32)
+        val = np.empty(nnz, np.float64)
+        lib().orc_mg_level_matrix(self._h, level, _p32(colptr), _p32(rowind), _p64(val))
+        return CSC(n, n, colptr, rowind, val)
+
+    def transfer(self, level, which):
+        """which: 'P' (n_h x n_H) or 'R' (n_H x n_h) between level and level+1."""
+        w = 1 if which == "R" else 0
+        n_h, n_H = self.n_dofs(level), self.n_dofs(level + 1)
+        rows, cols = (n_H, n_h) if w else (n_h, n_H)
+        nnz = lib().orc_mg_transfer_nnz(self._h, level, w)
+        colptr = np.empty(cols + 1, np.int32)
+        rowind = np.empty(nnz, np.int32)
+        val = np.empty(nnz, np.float64)
+        lib().orc_mg_transfer(self._h, level, w, _p32(colptr), _p32(rowind), _p64(val))
+        return CSC(rows, cols, colptr, rowind, val)
+
+    def get_vec(self, level, which):
+        out = np.empty(self.n_dofs(level), np.float64)
+        lib().orc_mg_get_vec(self._h, level, {"u": 0, "f": 1, "r": 2}[which], _p64(out))
+        return out
+
+    def set_vec(self, level, which, v):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        assert v.size == self.n_dofs(level)
+        lib().orc_mg_set_vec(self._h, level, {"u": 0, "f": 1, "r": 2}[which], _p64(v))
+
+    def coarse_halfbw(self):
+        return int(lib().orc_mg_coarse_halfbw(self._h))
+
+    def vcycle(self):
+        lib().orc_mg_vcycle(self._h)
+
+    def rss(self):
+        return lib().orc_mg_rss(self._h)
+
+    def solve(self, tol=1e-9, every=10, n_iters=100):
+        """Returns (iters, converged, last_rss, trajectory-of-rss-checks)."""
+        conv = C.c_int(0)
+        last = C.c_double(0)
+        cap = n_iters // max(every, 1) + 1
+        traj = np.zeros(cap, np.float64)
+        it = lib().orc_mg_solve(self._h, tol, every, n_iters, C.byref(conv),
+                                C.byref(last), _p64(traj), cap)
+        k = int(it) // every
+        return int(it), bool(conv.value), last.value, traj[:k].copy()
+
+    def time_vcycles(self, n):
+        return lib().orc_mg_time_vcycles(self._h, n)

@@ -1,0 +1,188 @@
+"""Pins the CPU oracle (oracle/amg_oracle.cpp) against every known-answer value
+the reference publishes for the V-cycle path.
+
+The reference holds no golden vectors; its only published numbers are the
+six-digit values printed by test/testlib.cpp:166-170,188-195,203-205 and shown in
+image/README/output.png.  KAT-4 values come from the survey's independent
+SciPy restatement (different coarse solver, so agreement ~1e-12 relative).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def sig6(x):
+    return float(f"{x:.5e}")
+
+
+def test_kat1_level_sizes(oracle):
+    # testlib.cpp:147-181 + output.png
+    A, b = oracle.laplacian(35), oracle.rhs(35)
+    mg = oracle.Multigrid(A, b, 8)
+    assert [mg.n_dofs(l) for l in range(8)] == [1225, 612, 305, 152, 75, 37, 18, 8]
+    # the reference's own assertion (testlib.cpp:178-180): strictly decreasing
+    for l in range(1, 8):
+        assert mg.level_matrix(l - 1).nnz > mg.level_matrix(l).nnz or l > 5
+        assert mg.n_dofs(l - 1) > mg.n_dofs(l)
+
+
+def test_kat2_amg_35_iterations(oracle):
+    # testlib.cpp:158-159,203-206: Multigrid(.., 8, 1e-9, 5, 100).solve()
+    A, b = oracle.laplacian(35), oracle.rhs(35)
+    mg = oracle.Multigrid(A, b, 8)
+    it, conv, last, traj = mg.solve(1e-9, 5, 100)
+    assert it == 35 and conv                      # "AMG converged after 35 iterations."
+    err = oracle.rss(A, mg.get_vec(0, "u"), b)
+    assert f"{err:.5e}" == "7.19199e-11"          # "AMG error: 7.19199e-11"
+    assert err < 1e-9                              # testlib.cpp:206
+    # SURVEY section 6 trajectory (independent restatement)
+    ref = [10.128102564, 0.139287315, 1.9329306e-3, 2.6844575e-5, 3.7284011e-7,
+           5.1783012e-9, 7.191993826e-11]
+    np.testing.assert_allclose(traj, ref, rtol=2e-8)
+
+
+def test_kat3_spgs_900_iterations(oracle):
+    # testlib.cpp:188-196: SparseGaussSeidel(1e-9, 100, 1000)
+    A, b = oracle.laplacian(35), oracle.rhs(35)
+    u, it, conv = oracle.smooth(oracle.SM_SPGS, A, np.zeros(1225), b,
+                                n_iters=1000, tol=1e-9, every=100)
+    assert it == 900 and conv                      # "SPGS converged after 900 iterations."
+    err = oracle.rss(A, u, b)
+    assert f"{err:.5e}" == "8.69692e-10"          # "SPGS error: 8.69692e-10"
+    np.testing.assert_allclose(err, 8.696923549e-10, rtol=1e-9)
+    # testlib.cpp:212  amg_u.isApprox(spgs_u_h, 1e-6): passes narrowly (8.47e-7)
+    mg = oracle.Multigrid(A, b, 8)
+    mg.solve(1e-9, 5, 100)
+    um = mg.get_vec(0, "u")
+    rel = np.linalg.norm(um - u) / min(np.linalg.norm(um), np.linalg.norm(u))
+    assert rel <= 1e-6
+    np.testing.assert_allclose(rel, 8.47e-7, rtol=2e-3)
+
+
+def test_kat4_config1_trajectory(oracle):
+    # BASELINE config 1: 128^2, 3 levels, default SpGS, zero start
+    n = 128
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    h = oracle.grid_spacing_h(n)
+    np.testing.assert_allclose(1.0 / (h * h), 4160.25, rtol=1e-15)
+    assert b[0] == 1.9068759825292718e-08
+    np.testing.assert_allclose(b[8255], 4.99399435541588, rtol=1e-15)
+    np.testing.assert_allclose(b.sum(), 6534.786943504223, rtol=1e-13)
+    d = A.to_scipy().diagonal()
+    assert np.all(d == -16641.0)
+    mg = oracle.Multigrid(A, b, 3)
+    # KAT-5 structure counts (structural zeros kept)
+    got = [(mg.n_dofs(l), mg.level_matrix(l).nnz) for l in range(3)]
+    assert got == [(16384, 81408), (8191, 73333), (4095, 36661)]
+    A1 = mg.level_matrix(1)
+    assert int((A1.val != 0).sum()) == 57207
+    # level-1 interior row stencil, in units of 1/h^2
+    S = A1.to_scipy().tocsr()
+    k = 64 * 40 + 20
+    row = S.getrow(k)
+    offs = dict(zip((row.indices - k).tolist(), (row.data * h * h).tolist()))
+    want = {-65: 0.25, -64: 1.5, -63: 0.25, -1: 0.0, 0: -4.0, 1: 0.0,
+            63: 0.25, 64: 1.5, 65: 0.25}
+    assert set(offs) == set(want)
+    for o, v in want.items():
+        assert abs(offs[o] - v) < 1e-12
+    ref = [631.3098481309848, 27.73371268868743, 1.4369747655188343,
+           0.0746496285091653, 3.8738631903892312e-3, 2.0090265010435648e-4,
+           1.0416114206372691e-5, 5.39980944046374e-7, 2.7992084641058298e-8,
+           1.4510712149626743e-9, 7.522177511818504e-11, 3.899432065889161e-12]
+    got = []
+    for _ in range(12):
+        mg.vcycle()
+        got.append(mg.rss())
+    np.testing.assert_allclose(got, ref, rtol=2e-7)   # last entries sit at rounding level
+    np.testing.assert_allclose(got[:8], ref[:8], rtol=1e-10)
+    u = mg.get_vec(0, "u")
+    np.testing.assert_allclose(np.linalg.norm(u), 18.439940504440255, rtol=1e-12)
+    np.testing.assert_allclose(u[8255], -0.37883470012055376, rtol=1e-12)
+
+
+def test_kat5_structure_counts_config2_prefix(oracle):
+    # SURVEY section 8 preamble, config 2 (1024^2): first three levels
+    n = 256  # same formulae, small enough for the CPU suite: check C/F + sizes
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    mg = oracle.Multigrid(A, b, 5)
+    sizes = [mg.n_dofs(l) for l in range(5)]
+    assert sizes == [65536, 32767, 16383, 8191, 4095]
+    # C/F splitting: coarse dof j <-> fine dof 2j+1, P column j =
+    # {0.5, 1.0, 0.5} on rows {2j, 2j+1, 2j+2}; R = P^T
+    for l in range(4):
+        P = mg.transfer(l, "P")
+        nH = sizes[l + 1]
+        assert P.rows == sizes[l] and P.cols == nH
+        assert np.array_equal(P.colptr, 3 * np.arange(nH + 1, dtype=np.int32))
+        j = np.arange(nH)
+        assert np.array_equal(P.rowind.reshape(nH, 3),
+                              np.stack([2 * j, 2 * j + 1, 2 * j + 2], 1))
+        assert np.array_equal(P.val.reshape(nH, 3), np.tile([0.5, 1.0, 0.5], (nH, 1)))
+        R = mg.transfer(l, "R")
+        assert (R.to_scipy() != P.to_scipy().T).nnz == 0
+
+
+def test_kat6_tiny_smoothers_match_direct(oracle):
+    # testlib.cpp:19-35,74-107: 4-dof system; Jacobi(100), SOR(100), SpGS(100)
+    # vs the direct solution, isApprox(..., 1e-9)
+    A, b = oracle.laplacian(2), oracle.rhs(2)
+    assert b.size == 4                                          # :28
+    exact = np.linalg.solve(A.to_scipy().toarray(), b)
+    x, w = oracle.band_solve(A, b)
+    np.testing.assert_allclose(x, exact, rtol=1e-13)
+    for kind in (oracle.SM_REF_JACOBI, oracle.SM_SOR, oracle.SM_SPGS):
+        # (size_t) ctor => n_iters=100, every=100 (base default), omega stays 1
+        u, it, _ = oracle.smooth(kind, A, np.zeros(4), b, n_iters=100, tol=1e-9, every=100)
+        d = np.linalg.norm(u - exact) ** 2
+        assert d <= 1e-18 * min(np.dot(u, u), np.dot(exact, exact))
+    # :60-62
+    assert oracle.points_n_from_grid_spacing_h(oracle.grid_spacing_h(2)) == 2
+
+
+def test_linear_interpolator_shapes(oracle):
+    # testlib.cpp:119-128: make_operators(7,3,0) and (24,11,0)
+    P = oracle.make_P(7, 3).to_scipy().toarray()
+    want = np.zeros((7, 3))
+    for j in range(3):
+        want[2 * j, j], want[2 * j + 1, j], want[2 * j + 2, j] = 0.5, 1.0, 0.5
+    assert np.array_equal(P, want)
+    P = oracle.make_P(24, 11)
+    assert P.nnz == 33 and P.rowind.max() == 22   # fine row 23 never corrected (n_h even)
+
+
+def test_eigen_order_primitives_vs_scipy(oracle):
+    # residual / spmv / spgemm agree with SciPy up to summation order
+    rng = np.random.default_rng(0)
+    A = oracle.laplacian(17)
+    u, f = rng.standard_normal(289), rng.standard_normal(289)
+    S = A.to_scipy()
+    np.testing.assert_allclose(oracle.residual(A, u, f), f - S @ u, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(oracle.rss(A, u, f), np.sum((f - S @ u) ** 2), rtol=1e-12)
+    mg = oracle.Multigrid(A, f, 3)
+    for l in range(2):
+        Ah, P, R = mg.level_matrix(l).to_scipy(), mg.transfer(l, "P").to_scipy(), \
+            mg.transfer(l, "R").to_scipy()
+        AH = mg.level_matrix(l + 1).to_scipy()
+        D = (R @ (Ah @ P) - AH)
+        assert abs(D).max() <= 1e-12 * abs(AH).max()
+
+
+def test_golden_fixture_matches_oracle(oracle):
+    """tests/golden/kat_config1.json is generated by tests/golden/make_golden.py
+    from this oracle; it is what the GPU tests compare against on the GPU box."""
+    path = os.path.join(GOLD, "kat_config1.json")
+    if not os.path.exists(path):
+        pytest.skip("golden fixture not generated yet")
+    g = json.load(open(path))
+    A, b = oracle.laplacian(g["n"]), oracle.rhs(g["n"])
+    mg = oracle.Multigrid(A, b, g["n_levels"])
+    got = []
+    for _ in range(len(g["rss"])):
+        mg.vcycle()
+        got.append(mg.rss())
+    assert got == g["rss"]
