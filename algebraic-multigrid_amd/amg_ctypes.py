@@ -1,0 +1,380 @@
+"""ctypes binding of libamg_hip.so (C ABI: include/amg_hip.h).
+
+Thin host-side mirror used by tests/, bench.py and the multi-GPU driver.  It
+contains no arithmetic: every operation is a call through the C ABI into the
+HIP kernels.  If the shared library is missing the import fails loudly; if no
+HIP device is present every compute call raises AmgHipError (status EHIP) --
+there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libamg_hip.so")
+
+OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED = 0, 1, 2, 3, 4
+SM_SPGS, SM_REF_JACOBI, SM_SOR, SM_JACOBI, SM_MULTICOLOR_GS = 0, 1, 2, 3, 4
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+_i64p = C.POINTER(C.c_int64)
+
+
+class AmgHipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"amg_hip status {status}: {msg}")
+        self.status = status
+        self.message = msg
+
+
+class Options(C.Structure):
+    _fields_ = [("smoother", C.c_int32), ("smoother_iters", C.c_int32),
+                ("omega", C.c_double), ("device", C.c_int32), ("use_graph", C.c_int32),
+                ("stencil_transfers", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+# name -> (restype, argtypes).  Must list EVERY symbol include/amg_hip.h declares
+# (tests/test_cabi_symbols.py checks the header against this table).
+_SIGS = {
+    "amg_hip_last_error": (C.c_char_p, []),
+    "amg_hip_default_options": (None, [C.POINTER(Options)]),
+    "amg_hip_device_count": (C.c_int, []),
+    "amg_hip_create": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_int32,
+                                 C.POINTER(Options), C.POINTER(C.c_void_p)]),
+    "amg_hip_create_custom": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_int32,
+                                        C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_f64p),
+                                        C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_f64p),
+                                        C.POINTER(Options), C.POINTER(C.c_void_p)]),
+    "amg_hip_destroy": (None, [C.c_void_p]),
+    "amg_hip_vcycle": (C.c_int, [C.c_void_p]),
+    "amg_hip_vcycles": (C.c_int, [C.c_void_p, C.c_int32]),
+    "amg_hip_sync": (C.c_int, [C.c_void_p]),
+    "amg_hip_solve": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_int64, _i64p, _f64p,
+                                _i32p]),
+    "amg_hip_rss": (C.c_int, [C.c_void_p, _f64p]),
+    "amg_hip_n_levels": (C.c_int32, [C.c_void_p]),
+    "amg_hip_get_n_dofs": (C.c_int64, [C.c_void_p, C.c_int32]),
+    "amg_hip_get_level_nnz": (C.c_int64, [C.c_void_p, C.c_int32]),
+    "amg_hip_get_level_matrix": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, _f64p]),
+    "amg_hip_get_transfer_nnz": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
+    "amg_hip_get_transfer": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i32p, _f64p]),
+    "amg_hip_get_vec": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p]),
+    "amg_hip_set_vec": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p]),
+    "amg_hip_coarse_halfbw": (C.c_int64, [C.c_void_p]),
+    "amg_hip_get_colors": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p]),
+    "amg_hip_cycle_bytes": (C.c_int, [C.c_void_p, _f64p, _f64p]),
+    "amg_hip_smooth": (C.c_int, [C.c_int32, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p,
+                                 C.c_double, C.c_double, C.c_int64, C.c_int64, _i64p, _i32p]),
+    "amg_hip_spgs_sweep": (C.c_int, [C.c_int32, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]),
+    "amg_hip_residual": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, _f64p]),
+    "amg_hip_spmv": (C.c_int, [C.c_int64, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]),
+    "amg_hip_linear_restrict": (C.c_int, [C.c_int64, C.c_int64, _f64p, _f64p]),
+    "amg_hip_linear_prolong_add": (C.c_int, [C.c_int64, C.c_int64, _f64p, _f64p]),
+    "amg_hip_rss_host": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, _f64p]),
+    "amg_hip_coarse_solve": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, _i64p]),
+    "amg_hip_laplacian": (C.c_int64, [C.c_int32, C.c_int64, _i32p, _i32p, _f64p]),
+    "amg_hip_rhs": (C.c_int, [C.c_int32, C.c_int64, _f64p]),
+    "amg_hip_csr_shape": (C.c_int, [C.c_int64, _i32p, _i32p, _i32p]),
+    "amg_hip_dev_residual": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "amg_hip_dev_jacobi": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_double, C.c_int64, C.c_void_p]),
+    "amg_hip_dev_spmv": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "amg_hip_dev_axpy1": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "amg_hip_dev_sumsq": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `make -C {_HERE}` "
+                "(or __graft_entry__.build()); there is no fallback implementation")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _chk(status):
+    if status != OK:
+        raise AmgHipError(status, lib().amg_hip_last_error().decode())
+
+
+def _a32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _a64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p32(a):
+    return a.ctypes.data_as(_i32p)
+
+
+def _p64(a):
+    return a.ctypes.data_as(_f64p)
+
+
+def device_count():
+    return lib().amg_hip_device_count()
+
+
+# ---- Grid<double> ------------------------------------------------------------
+def laplacian(n, dim=2):
+    """grid.hpp:88-98.  Returns (colptr, rowind, val) of the CSC matrix."""
+    nnz = lib().amg_hip_laplacian(dim, n, None, None, None)
+    if nnz < 0:
+        raise AmgHipError(EINVAL, lib().amg_hip_last_error().decode())
+    N = n ** dim
+    colptr = np.empty(N + 1, np.int32)
+    rowind = np.empty(nnz, np.int32)
+    val = np.empty(nnz, np.float64)
+    got = lib().amg_hip_laplacian(dim, n, _p32(colptr), _p32(rowind), _p64(val))
+    assert got == nnz
+    return colptr, rowind, val
+
+
+def rhs(n, dim=2):
+    b = np.empty(n ** dim, np.float64)
+    _chk(lib().amg_hip_rhs(dim, n, _p64(b)))
+    return b
+
+
+# ---- AMG::Multigrid<double> ----------------------------------------------------
+class Multigrid:
+    """Mirror of AMG::Multigrid<double> (multigrid.hpp) over the C ABI."""
+
+    def __init__(self, colptr, rowind, val, b, n_levels, smoother=SM_SPGS,
+                 smoother_iters=1, omega=1.0, tolerance=1e-9, compute_error_every_n_iters=10,
+                 n_iters=100, device=-1, use_graph=True, stencil_transfers=True,
+                 transfers=None):
+        # multigrid.hpp:165-178 (same checks, same order)
+        if compute_error_every_n_iters > n_iters:
+            raise ValueError("`compute_error_every_n_iters` must be leq to `n_iters`, got "
+                             f"{compute_error_every_n_iters} and {n_iters}")
+        colptr, rowind, val, b = _a32(colptr), _a32(rowind), _a64(val), _a64(b)
+        n = colptr.size - 1
+        if n != b.size:
+            raise ValueError("`A` and `b` must have the same number of degrees of freedom, "
+                             f"got {n} and {b.size}")
+        self.tolerance = tolerance
+        self.every = compute_error_every_n_iters
+        self.n_iters = n_iters
+        o = Options()
+        lib().amg_hip_default_options(C.byref(o))
+        o.smoother, o.smoother_iters, o.omega = smoother, smoother_iters, omega
+        o.device, o.use_graph, o.stencil_transfers = device, int(use_graph), int(stencil_transfers)
+        h = C.c_void_p()
+        if transfers is None:
+            st = lib().amg_hip_create(n, _p32(colptr), _p32(rowind), _p64(val), _p64(b),
+                                      n_levels, C.byref(o), C.byref(h))
+        else:
+            # transfers: list over levels of (P_csc, R_csc), each (colptr,rowind,val)
+            keep = []
+            arrs = [[], [], [], [], [], []]
+            for (P, R) in transfers:
+                for k, a in enumerate((_a32(P[0]), _a32(P[1]), _a64(P[2]),
+                                       _a32(R[0]), _a32(R[1]), _a64(R[2]))):
+                    keep.append(a)
+                    arrs[k].append(a)
+            nl = len(transfers)
+
+            def tab(lst, ptr_t, conv):
+                t = (ptr_t * max(nl, 1))()
+                for i, a in enumerate(lst):
+                    t[i] = conv(a)
+                return t
+            st = lib().amg_hip_create_custom(
+                n, _p32(colptr), _p32(rowind), _p64(val), _p64(b), n_levels,
+                tab(arrs[0], _i32p, _p32), tab(arrs[1], _i32p, _p32), tab(arrs[2], _f64p, _p64),
+                tab(arrs[3], _i32p, _p32), tab(arrs[4], _i32p, _p32), tab(arrs[5], _f64p, _p64),
+                C.byref(o), C.byref(h))
+        if st == EINVAL:
+            raise ValueError(lib().amg_hip_last_error().decode())
+        _chk(st)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().amg_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def n_levels(self):
+        return lib().amg_hip_n_levels(self._h)
+
+    def get_n_dofs(self, level):
+        return int(lib().amg_hip_get_n_dofs(self._h, level))
+
+    def get_coefficient_matrix(self, level):
+        n = self.get_n_dofs(level)
+        nnz = lib().amg_hip_get_level_nnz(self._h, level)
+        colptr = np.empty(n + 1, np.int32)
+        rowind = np.empty(nnz, np.int32)
+        val = np.empty(nnz, np.float64)
+        _chk(lib().amg_hip_get_level_matrix(self._h, level, _p32(colptr), _p32(rowind), _p64(val)))
+        return colptr, rowind, val
+
+    def get_transfer(self, level, which):
+        w = 1 if which == "R" else 0
+        nnz = lib().amg_hip_get_transfer_nnz(self._h, level, w)
+        if nnz < 0:
+            raise ValueError("level out of range")
+        n_h, n_H = self.get_n_dofs(level), self.get_n_dofs(level + 1)
+        cols = n_h if w else n_H
+        colptr = np.empty(cols + 1, np.int32)
+        rowind = np.empty(nnz, np.int32)
+        val = np.empty(nnz, np.float64)
+        _chk(lib().amg_hip_get_transfer(self._h, level, w, _p32(colptr), _p32(rowind), _p64(val)))
+        return colptr, rowind, val
+
+    def _get(self, level, which):
+        out = np.empty(self.get_n_dofs(level), np.float64)
+        _chk(lib().amg_hip_get_vec(self._h, level, which, _p64(out)))
+        return out
+
+    def get_soln(self, level=0):
+        return self._get(level, 0)
+
+    def get_rhs(self, level=0):
+        return self._get(level, 1)
+
+    def get_residual(self, level=0):
+        return self._get(level, 2)
+
+    def set_vec(self, level, which, v):
+        v = _a64(v)
+        assert v.size == self.get_n_dofs(level)
+        _chk(lib().amg_hip_set_vec(self._h, level, {"u": 0, "f": 1, "r": 2}[which], _p64(v)))
+
+    def get_tolerance(self):
+        return self.tolerance
+
+    def coarse_halfbw(self):
+        return int(lib().amg_hip_coarse_halfbw(self._h))
+
+    def get_colors(self, level):
+        color = np.empty(self.get_n_dofs(level), np.int32)
+        nc = C.c_int32(0)
+        _chk(lib().amg_hip_get_colors(self._h, level, _p32(color), C.byref(nc)))
+        return color, nc.value
+
+    def cycle_bytes(self):
+        a, b = C.c_double(0), C.c_double(0)
+        _chk(lib().amg_hip_cycle_bytes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def vcycle(self, n=1):
+        _chk(lib().amg_hip_vcycles(self._h, n))
+
+    def sync(self):
+        _chk(lib().amg_hip_sync(self._h))
+
+    def rss(self):
+        out = C.c_double(0)
+        _chk(lib().amg_hip_rss(self._h, C.byref(out)))
+        return out.value
+
+    def solve(self):
+        """multigrid.hpp:311-337.  Returns (u, iters, converged, last_rss) and
+        prints the reference's convergence line."""
+        it, last, conv = C.c_int64(0), C.c_double(0), C.c_int32(0)
+        _chk(lib().amg_hip_solve(self._h, self.tolerance, self.every, self.n_iters,
+                                 C.byref(it), C.byref(last), C.byref(conv)))
+        if conv.value:
+            print(f"AMG converged after {it.value} iterations.")
+        else:
+            print(f"AMG did not converge after {it.value} iterations.")
+        return self.get_soln(0), it.value, bool(conv.value), last.value
+
+
+# ---- stand-alone plug-in operations ---------------------------------------------
+def smooth(kind, colptr, rowind, val, u, b, n_iters=1, omega=1.0, tol=1e-9, every=0):
+    colptr, rowind, val, b = _a32(colptr), _a32(rowind), _a64(val), _a64(b)
+    u = np.array(u, dtype=np.float64, copy=True)
+    it, conv = C.c_int64(0), C.c_int32(0)
+    st = lib().amg_hip_smooth(kind, colptr.size - 1, _p32(colptr), _p32(rowind), _p64(val),
+                              _p64(u), _p64(b), omega, tol, every, n_iters, C.byref(it),
+                              C.byref(conv))
+    if st == EINVAL:
+        raise ValueError(lib().amg_hip_last_error().decode())
+    _chk(st)
+    return u, it.value, bool(conv.value)
+
+
+def spgs_sweep(direction, colptr, rowind, val, u, b):
+    colptr, rowind, val, b = _a32(colptr), _a32(rowind), _a64(val), _a64(b)
+    u = np.array(u, dtype=np.float64, copy=True)
+    _chk(lib().amg_hip_spgs_sweep(direction, colptr.size - 1, _p32(colptr), _p32(rowind),
+                                  _p64(val), _p64(u), _p64(b)))
+    return u
+
+
+def residual(colptr, rowind, val, u, f):
+    colptr, rowind, val, u, f = _a32(colptr), _a32(rowind), _a64(val), _a64(u), _a64(f)
+    r = np.empty(colptr.size - 1, np.float64)
+    _chk(lib().amg_hip_residual(colptr.size - 1, _p32(colptr), _p32(rowind), _p64(val),
+                                _p64(u), _p64(f), _p64(r)))
+    return r
+
+
+def spmv(rows, cols, colptr, rowind, val, v):
+    colptr, rowind, val, v = _a32(colptr), _a32(rowind), _a64(val), _a64(v)
+    out = np.empty(rows, np.float64)
+    _chk(lib().amg_hip_spmv(rows, cols, _p32(colptr), _p32(rowind), _p64(val), _p64(v), _p64(out)))
+    return out
+
+
+def linear_restrict(n_h, n_H, r):
+    r = _a64(r)
+    out = np.empty(n_H, np.float64)
+    _chk(lib().amg_hip_linear_restrict(n_h, n_H, _p64(r), _p64(out)))
+    return out
+
+
+def linear_prolong_add(n_h, n_H, u_H, u_h):
+    u_H = _a64(u_H)
+    u_h = np.array(u_h, dtype=np.float64, copy=True)
+    _chk(lib().amg_hip_linear_prolong_add(n_h, n_H, _p64(u_H), _p64(u_h)))
+    return u_h
+
+
+def rss(colptr, rowind, val, u, b):
+    colptr, rowind, val, u, b = _a32(colptr), _a32(rowind), _a64(val), _a64(u), _a64(b)
+    out = C.c_double(0)
+    _chk(lib().amg_hip_rss_host(colptr.size - 1, _p32(colptr), _p32(rowind), _p64(val),
+                                _p64(u), _p64(b), C.byref(out)))
+    return out.value
+
+
+def coarse_solve(colptr, rowind, val, f):
+    colptr, rowind, val, f = _a32(colptr), _a32(rowind), _a64(val), _a64(f)
+    x = np.empty(f.size, np.float64)
+    w = C.c_int64(0)
+    _chk(lib().amg_hip_coarse_solve(f.size, _p32(colptr), _p32(rowind), _p64(val), _p64(f),
+                                    _p64(x), C.byref(w)))
+    return x, w.value
+
+
+def csr_shape(rowptr):
+    rowptr = _a32(rowptr)
+    mb, mr = C.c_int32(0), C.c_int32(0)
+    _chk(lib().amg_hip_csr_shape(rowptr.size - 1, _p32(rowptr), C.byref(mb), C.byref(mr)))
+    return mb.value, mr.value

@@ -1,0 +1,410 @@
+// Host-side SETUP of the multigrid hierarchy (see host_setup.hpp).
+#include "host_setup.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace amg_hip {
+
+Sparse from_raw(int64_t n_outer, int64_t n_inner, const int32_t* ptr,
+                const int32_t* idx, const double* val) {
+  Sparse M;
+  M.n_outer = n_outer;
+  M.n_inner = n_inner;
+  M.ptr.assign(ptr, ptr + n_outer + 1);
+  const int64_t nnz = ptr[n_outer];
+  M.idx.assign(idx, idx + nnz);
+  M.val.assign(val, val + nnz);
+  return M;
+}
+
+std::string validate(const Sparse& M, const char* name) {
+  const std::string nm(name);
+  if (M.n_outer < 0 || M.n_inner < 0) return nm + ": negative dimension";
+  if ((int64_t)M.ptr.size() != M.n_outer + 1) return nm + ": bad pointer array";
+  if (M.ptr[0] != 0) return nm + ": pointer array must start at 0";
+  for (int64_t o = 0; o < M.n_outer; ++o) {
+    if (M.ptr[o + 1] < M.ptr[o]) return nm + ": pointer array not monotone";
+    for (int32_t p = M.ptr[o]; p < M.ptr[o + 1]; ++p) {
+      if (M.idx[p] < 0 || M.idx[p] >= M.n_inner)
+        return nm + ": inner index out of range";
+      if (p > M.ptr[o] && M.idx[p] <= M.idx[p - 1])
+        return nm + ": inner indices must be strictly ascending (compressed, "
+                    "no duplicates)";
+    }
+  }
+  return "";
+}
+
+Sparse transpose(const Sparse& M) {
+  Sparse T;
+  T.n_outer = M.n_inner;
+  T.n_inner = M.n_outer;
+  T.ptr.assign(T.n_outer + 1, 0);
+  T.idx.resize(M.nnz());
+  T.val.resize(M.nnz());
+  for (int32_t i : M.idx) T.ptr[i + 1]++;
+  for (int64_t o = 0; o < T.n_outer; ++o) T.ptr[o + 1] += T.ptr[o];
+  std::vector<int32_t> cursor(T.ptr.begin(), T.ptr.end() - 1);
+  for (int64_t o = 0; o < M.n_outer; ++o)
+    for (int32_t p = M.ptr[o]; p < M.ptr[o + 1]; ++p) {
+      const int32_t q = cursor[M.idx[p]]++;
+      T.idx[q] = (int32_t)o;
+      T.val[q] = M.val[p];
+    }
+  return T;
+}
+
+bool same_arrays(const Sparse& a, const Sparse& b) {
+  return a.n_outer == b.n_outer && a.n_inner == b.n_inner && a.ptr == b.ptr &&
+         a.idx == b.idx &&
+         std::memcmp(a.val.data(), b.val.data(), sizeof(double) * a.val.size()) == 0;
+}
+
+Sparse linear_P(int64_t n_h, int64_t n_H) {
+  Sparse P;  // CSC: outer = coarse column j
+  P.n_outer = n_H;
+  P.n_inner = n_h;
+  P.ptr.resize(n_H + 1);
+  P.ptr[0] = 0;
+  P.idx.reserve(3 * n_H);
+  P.val.reserve(3 * n_H);
+  static const double w3[3] = {0.5, 1.0, 0.5};
+  for (int64_t j = 0; j < n_H; ++j) {
+    for (int t = 0; t < 3; ++t) {
+      const int64_t i = 2 * j + t;
+      if (i < n_h) {
+        P.idx.push_back((int32_t)i);
+        P.val.push_back(w3[t]);
+      }
+    }
+    P.ptr[j + 1] = (int32_t)P.idx.size();
+  }
+  return P;
+}
+
+bool is_linear_P(const Sparse& P, int64_t n_h, int64_t n_H) {
+  return same_arrays(P, linear_P(n_h, n_H));
+}
+
+// ------------------------------------------------------------------ SpGEMM ---
+namespace {
+struct RowBlockOut {
+  std::vector<int32_t> cnt;  // entries per row of the block
+  std::vector<int32_t> idx;
+  std::vector<double> val;
+};
+
+void spgemm_rows(const Sparse& A, const Sparse& B, int64_t r0, int64_t r1,
+                 RowBlockOut* out) {
+  const int64_t nc = B.n_inner;
+  std::vector<int32_t> stamp(nc, -1);
+  std::vector<double> acc(nc);
+  std::vector<int32_t> touched;
+  out->cnt.assign(r1 - r0, 0);
+  for (int64_t i = r0; i < r1; ++i) {
+    touched.clear();
+    for (int32_t p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+      const int32_t k = A.idx[p];
+      const double a = A.val[p];
+      for (int32_t q = B.ptr[k]; q < B.ptr[k + 1]; ++q) {
+        const int32_t J = B.idx[q];
+        const double t = a * B.val[q];
+        if (stamp[J] != (int32_t)(i - r0)) {  // first touch: assign
+          stamp[J] = (int32_t)(i - r0);
+          acc[J] = t;
+          touched.push_back(J);
+        } else {
+          acc[J] += t;
+        }
+      }
+    }
+    std::sort(touched.begin(), touched.end());
+    out->cnt[i - r0] = (int32_t)touched.size();
+    for (int32_t J : touched) {
+      out->idx.push_back(J);
+      out->val.push_back(acc[J]);
+    }
+  }
+}
+}  // namespace
+
+Sparse spgemm_csr(const Sparse& A, const Sparse& B, int n_threads) {
+  const int64_t n = A.n_outer;
+  if (n_threads < 1) n_threads = 1;
+  // row blocks small enough that the per-block stamp (int32 of local row) works
+  int64_t nblk = std::max<int64_t>(n_threads, 1);
+  if (n < 4096) nblk = 1;
+  std::vector<RowBlockOut> parts(nblk);
+  std::vector<std::thread> th;
+  auto work = [&](int64_t b) {
+    const int64_t r0 = n * b / nblk, r1 = n * (b + 1) / nblk;
+    spgemm_rows(A, B, r0, r1, &parts[b]);
+  };
+  if (nblk == 1) {
+    work(0);
+  } else {
+    for (int64_t b = 0; b < nblk; ++b) th.emplace_back(work, b);
+    for (auto& t : th) t.join();
+  }
+  Sparse C;
+  C.n_outer = n;
+  C.n_inner = B.n_inner;
+  C.ptr.resize(n + 1);
+  C.ptr[0] = 0;
+  int64_t total = 0;
+  for (auto& p : parts) total += (int64_t)p.idx.size();
+  C.idx.resize(total);
+  C.val.resize(total);
+  int64_t row = 0, off = 0;
+  for (auto& p : parts) {
+    for (int32_t c : p.cnt) {
+      C.ptr[row + 1] = C.ptr[row] + c;
+      ++row;
+    }
+    std::memcpy(C.idx.data() + off, p.idx.data(), sizeof(int32_t) * p.idx.size());
+    std::memcpy(C.val.data() + off, p.val.data(), sizeof(double) * p.val.size());
+    off += (int64_t)p.idx.size();
+    RowBlockOut().cnt.swap(p.cnt);
+    std::vector<int32_t>().swap(p.idx);
+    std::vector<double>().swap(p.val);
+  }
+  return C;
+}
+
+Sparse galerkin_csr(const Sparse& Rr, const Sparse& Ar, const Sparse& Pr,
+                    int n_threads) {
+  Sparse AP = spgemm_csr(Ar, Pr, n_threads);
+  return spgemm_csr(Rr, AP, n_threads);
+}
+
+// ------------------------------------------------------------- banded LDL^T ---
+std::string band_factor(const Sparse& A, size_t max_bytes, BandFactor* out) {
+  const int64_t n = A.n_outer;
+  int64_t w = 0;
+  for (int64_t o = 0; o < n; ++o)
+    for (int32_t p = A.ptr[o]; p < A.ptr[o + 1]; ++p)
+      w = std::max<int64_t>(w, std::llabs((int64_t)A.idx[p] - o));
+  const int64_t W = w + 1;
+  if ((size_t)n * (size_t)W * sizeof(double) * 3 > max_bytes)
+    return "coarsest operator: band storage n*(w+1) = " + std::to_string(n) + "*" +
+           std::to_string(W) + " doubles exceeds the limit; use more levels";
+  // row-oriented work band: rb[i*W + d] = L[i, i-d], d = 0 holds D[i]
+  std::vector<double> rb((size_t)(n * W), 0.0);
+  for (int64_t o = 0; o < n; ++o)
+    for (int32_t p = A.ptr[o]; p < A.ptr[o + 1]; ++p) {
+      const int64_t i = A.idx[p];  // (i, o) with i >= o: lower triangle
+      if (i >= o) rb[i * W + (i - o)] = A.val[p];
+    }
+  std::vector<double> ld(W);  // ld[k-j0] = L[i,k]*D[k]
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t j0 = std::max<int64_t>(0, i - w);
+    for (int64_t j = j0; j < i; ++j) {
+      double s = rb[i * W + (i - j)];
+      for (int64_t k = std::max(j0, j - w); k < j; ++k)
+        s -= ld[k - j0] * rb[j * W + (j - k)];
+      ld[j - j0] = s;
+      rb[i * W + (i - j)] = s / rb[j * W];
+    }
+    double d = rb[i * W];
+    for (int64_t k = j0; k < i; ++k) d -= ld[k - j0] * rb[i * W + (i - k)];
+    if (d == 0.0 || !std::isfinite(d))
+      return "coarsest operator: zero or non-finite pivot in LDL^T at row " +
+             std::to_string(i);
+    rb[i * W] = d;
+  }
+  out->n = n;
+  out->w = w;
+  out->d.resize(n);
+  out->lcol.assign((size_t)(n * std::max<int64_t>(w, 1)), 0.0);
+  for (int64_t i = 0; i < n; ++i) {
+    out->d[i] = rb[i * W];
+    for (int64_t d = 1; d <= w && i - d >= 0; ++d)
+      out->lcol[(i - d) * w + (d - 1)] = rb[i * W + d];  // L[i, i-d] = L[(i-d)+d, i-d]
+  }
+  return "";
+}
+
+// ------------------------------------------------- exact lexicographic order ---
+std::string build_lex_schedule(const Sparse& M, bool backward, int32_t max_width,
+                               LexSchedule* S) {
+  const int64_t n = M.n_outer;
+  if (M.n_inner != n) return "lexicographic Gauss-Seidel needs a square matrix";
+  int32_t width = 0;
+  for (int64_t k = 0; k < n; ++k)
+    width = std::max(width, M.ptr[k + 1] - M.ptr[k]);
+  if (width > max_width)
+    return "exact lexicographic Gauss-Seidel kernel supports at most " +
+           std::to_string(max_width) + " entries per row, matrix has " +
+           std::to_string(width);
+  // Dependencies of row k in sweep order: every j "before" k that k reads
+  // (true dependency) or that reads k's OLD value (anti-dependency, matters
+  // only for structurally non-symmetric matrices).  Exact zeros are skipped.
+  const Sparse T = transpose(M);
+  std::vector<int32_t> lev(n, 0);
+  int32_t maxlev = 0;
+  auto before = [&](int64_t j, int64_t k) { return backward ? j > k : j < k; };
+  for (int64_t t = 0; t < n; ++t) {
+    const int64_t k = backward ? n - 1 - t : t;
+    int32_t l = 0;
+    for (int32_t p = M.ptr[k]; p < M.ptr[k + 1]; ++p) {
+      const int64_t j = M.idx[p];
+      if (j != k && M.val[p] != 0.0 && before(j, k)) l = std::max(l, lev[j] + 1);
+    }
+    for (int32_t p = T.ptr[k]; p < T.ptr[k + 1]; ++p) {
+      const int64_t j = T.idx[p];
+      if (j != k && T.val[p] != 0.0 && before(j, k)) l = std::max(l, lev[j] + 1);
+    }
+    lev[k] = l;
+    maxlev = std::max(maxlev, l);
+  }
+  const int64_t n_sets = n == 0 ? 0 : (int64_t)maxlev + 1;
+  const double avg = n_sets ? (double)n / (double)n_sets : 0.0;
+  int32_t block;
+  bool by_sets;
+  if (avg >= 256.0) { block = 1024; by_sets = true; }
+  else if (avg >= 32.0) { block = 256; by_sets = true; }
+  else { block = 64; by_sets = false; }
+
+  std::vector<int32_t> order(n);
+  if (by_sets) {  // counting sort by level, sweep order inside a level
+    std::vector<int64_t> start(n_sets + 1, 0);
+    for (int64_t k = 0; k < n; ++k) start[lev[k] + 1]++;
+    for (int64_t s = 0; s < n_sets; ++s) start[s + 1] += start[s];
+    for (int64_t t = 0; t < n; ++t) {
+      const int64_t k = backward ? n - 1 - t : t;
+      order[start[lev[k]]++] = (int32_t)k;
+    }
+  } else {
+    for (int64_t t = 0; t < n; ++t) order[t] = (int32_t)(backward ? n - 1 - t : t);
+  }
+  std::vector<int32_t> pos(n);
+  for (int64_t p = 0; p < n; ++p) pos[order[p]] = (int32_t)p;
+
+  S->block = block;
+  S->width = width;
+  S->n = n;
+  S->n_sets = n_sets;
+  const int64_t n_win = (n + block - 1) / block;
+  S->n_slots = n_win * block;
+  S->row.assign(S->n_slots, -1);
+  S->depth.assign(S->n_slots, 0);
+  S->win_depth.assign(n_win, 0);
+  S->col.assign((size_t)S->n_slots * width, -1);
+  S->val.assign((size_t)S->n_slots * width, 0.0);
+  S->src.assign((size_t)S->n_slots * width, -1);
+  for (int64_t p = 0; p < n; ++p) {
+    const int64_t k = order[p];
+    const int64_t w0 = (p / block) * block;
+    S->row[p] = (int32_t)k;
+    int32_t dep = 0;
+    int32_t e = 0;
+    for (int32_t q = M.ptr[k]; q < M.ptr[k + 1]; ++q, ++e) {
+      const int64_t j = M.idx[q];
+      const size_t at = (size_t)e * S->n_slots + p;
+      S->col[at] = (int32_t)j;
+      S->val[at] = M.val[q];
+      if (j != k && M.val[q] != 0.0 && before(j, k) && pos[j] >= w0) {
+        // producer sits in this window (necessarily in an earlier slot)
+        S->src[at] = (int16_t)(pos[j] - w0);
+        dep = std::max<int32_t>(dep, S->depth[pos[j]] + 1);
+      }
+    }
+    S->depth[p] = (int16_t)dep;
+    int32_t& wd = S->win_depth[p / block];
+    wd = std::max(wd, dep);
+  }
+  return "";
+}
+
+void greedy_coloring(const Sparse& M, std::vector<int32_t>* color,
+                     int32_t* n_colors) {
+  const int64_t n = M.n_outer;
+  const Sparse T = transpose(M);
+  color->assign(n, -1);
+  int32_t nc = 0;
+  std::vector<int32_t> mark;  // mark[c] = last row that saw colour c adjacent
+  for (int64_t k = 0; k < n; ++k) {
+    auto visit = [&](const Sparse& S) {
+      for (int32_t p = S.ptr[k]; p < S.ptr[k + 1]; ++p) {
+        const int64_t j = S.idx[p];
+        if (j == k || S.val[p] == 0.0) continue;
+        const int32_t c = (*color)[j];
+        if (c >= 0) mark[c] = (int32_t)k;
+      }
+    };
+    visit(M);
+    visit(T);
+    int32_t c = 0;
+    while (c < nc && mark[c] == (int32_t)k) ++c;
+    if (c == nc) {
+      ++nc;
+      mark.push_back(-1);
+    }
+    (*color)[k] = c;
+  }
+  *n_colors = nc;
+}
+
+// ---------------------------------------------------------------- grid.hpp ---
+Sparse laplacian(int dim, int64_t n) {
+  // grid.hpp:31,50-75,88-98.  D = tridiag(1,-2,1)/(h*h) with h = 2/(n+1);
+  // A = sum over axes of I (x) .. D .. (x) I.  Diagonal = D_ii added once per
+  // axis; every off-diagonal appears in exactly one Kronecker term.
+  const double h = 2.0 / (double)(n + 1);
+  const double hh = h * h;
+  const double off = 1.0 / hh;
+  const double dg = -2.0 / hh;
+  double diag = dg + dg;
+  if (dim == 3) diag = diag + dg;
+  int64_t N = n * n;
+  if (dim == 3) N *= n;
+  const int64_t strides[3] = {1, n, n * n};
+  Sparse A;
+  A.n_outer = A.n_inner = N;
+  A.ptr.resize(N + 1);
+  A.ptr[0] = 0;
+  A.idx.reserve((size_t)N * (2 * dim + 1));
+  A.val.reserve((size_t)N * (2 * dim + 1));
+  for (int64_t c = 0; c < N; ++c) {
+    int64_t coord[3] = {c % n, (c / n) % n, c / (n * n)};
+    for (int a = dim - 1; a >= 0; --a)  // lower neighbours, ascending index
+      if (coord[a] > 0) {
+        A.idx.push_back((int32_t)(c - strides[a]));
+        A.val.push_back(off);
+      }
+    A.idx.push_back((int32_t)c);
+    A.val.push_back(diag);
+    for (int a = 0; a < dim; ++a)
+      if (coord[a] + 1 < n) {
+        A.idx.push_back((int32_t)(c + strides[a]));
+        A.val.push_back(off);
+      }
+    A.ptr[c + 1] = (int32_t)A.idx.size();
+  }
+  return A;
+}
+
+void rhs(int dim, int64_t n, double* b) {
+  // grid.hpp:108-140 with Eigen's LinSpaced(n+2, -1, 1):
+  // x_i = (i == n+1) ? 1 : -1 + i*step, step = 2/(n+1).
+  const int64_t np = n + 2;
+  const double step = (1.0 - (-1.0)) / (double)(np - 1);
+  std::vector<double> x(np);
+  for (int64_t i = 0; i < np; ++i) x[i] = (i == np - 1) ? 1.0 : -1.0 + (double)i * step;
+  int64_t dof = 0;
+  if (dim == 2) {
+    for (int64_t j = 1; j <= n; ++j)
+      for (int64_t i = 1; i <= n; ++i)
+        b[dof++] = 5 * std::exp(-10 * (x[j] * x[j] + x[i] * x[i]));
+  } else {
+    for (int64_t k = 1; k <= n; ++k)
+      for (int64_t j = 1; j <= n; ++j)
+        for (int64_t i = 1; i <= n; ++i)
+          b[dof++] = 5 * std::exp(-10 * ((x[k] * x[k] + x[j] * x[j]) + x[i] * x[i]));
+  }
+}
+
+}  // namespace amg_hip

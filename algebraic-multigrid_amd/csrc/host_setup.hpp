@@ -1,0 +1,98 @@
+// Host-side SETUP of the multigrid hierarchy (runs once per solver; the
+// reference does the same work in Multigrid's constructor, multigrid.hpp:151-244).
+// Product code: shares nothing with oracle/.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace amg_hip {
+
+// Compressed sparse storage.  As "CSC": outer = column, inner = row index.
+// As "CSR": outer = row, inner = column index.  Inner indices ascending.
+struct Sparse {
+  int64_t n_outer = 0, n_inner = 0;
+  std::vector<int32_t> ptr;  // n_outer + 1
+  std::vector<int32_t> idx;  // nnz
+  std::vector<double> val;   // nnz
+  int64_t nnz() const { return (int64_t)idx.size(); }
+};
+
+Sparse from_raw(int64_t n_outer, int64_t n_inner, const int32_t* ptr,
+                const int32_t* idx, const double* val);
+// Validates a compressed matrix (monotone ptr, indices in range and strictly
+// ascending).  Returns "" when fine.
+std::string validate(const Sparse& M, const char* name);
+
+// Storage transpose: CSC(M) -> CSC(M^T) == CSR(M).
+Sparse transpose(const Sparse& M);
+bool same_arrays(const Sparse& a, const Sparse& b);  // bitwise equality
+
+// interpolator.hpp:106-141, LinearInterpolator::make_operators: returns P in
+// CSC (n_h x n_H); R = transpose(P).
+Sparse linear_P(int64_t n_h, int64_t n_H);
+// true when P (CSC, n_h x n_H) is exactly what linear_P produces
+bool is_linear_P(const Sparse& P, int64_t n_h, int64_t n_H);
+
+// multigrid.hpp:127-130
+inline int64_t coarse_dofs(int64_t n_h) { return (n_h + 1) / 2 - 1; }
+
+// C = A * B, all three in row-major CSR, Gustavson row by row.  For a fixed
+// output entry (i, J) the products are added in ascending k, which is the
+// order Eigen's conservative column-major product uses (multigrid.hpp:222);
+// entries that cancel to exactly 0.0 stay in the pattern.  Multi-threaded over
+// row blocks (results do not depend on the thread count).
+Sparse spgemm_csr(const Sparse& A, const Sparse& B, int n_threads);
+
+// Galerkin coarse operator A_H = R (A P) given the row-major forms
+// CSR(R), CSR(A), CSR(P).  Returns CSR(A_H).
+Sparse galerkin_csr(const Sparse& Rr, const Sparse& Ar, const Sparse& Pr,
+                    int n_threads);
+
+// ---- coarsest level: banded LDL^T (replaces Eigen::SimplicialLDLT) ---------
+struct BandFactor {
+  int64_t n = 0, w = 0;
+  // Column-major-by-diagonal layout chosen for the device solve kernel:
+  // lcol[k*w + (d-1)] = L[k+d, k]  (d = 1..w), zero past the matrix end;
+  // dinv is NOT stored: the solve divides by d[k] (IEEE divide, no reciprocal).
+  std::vector<double> lcol;
+  std::vector<double> d;
+};
+// `A` symmetric, CSC or CSR (same thing).  Fails (returns message) on a zero
+// pivot or when the band would need more than `max_bytes`.
+std::string band_factor(const Sparse& A, size_t max_bytes, BandFactor* out);
+
+// ---- exact lexicographic Gauss-Seidel schedule ------------------------------
+// Rows are executed in `order`; rows inside one window of `block` consecutive
+// slots that depend on an earlier slot of the same window get `depth` > 0.
+struct LexSchedule {
+  int32_t block = 64;    // window size = threads per workgroup
+  int32_t width = 0;     // ELL width (max entries per row)
+  int64_t n = 0;         // rows
+  int64_t n_slots = 0;   // n rounded up to a multiple of block
+  std::vector<int32_t> row;     // n_slots: row of each slot (-1 = padding)
+  std::vector<int16_t> depth;   // n_slots
+  std::vector<int32_t> win_depth;  // per window: max depth
+  // ELL arrays, entry e of slot s at [e*n_slots + s]; col = -1 pads.
+  std::vector<int32_t> col;
+  std::vector<double> val;
+  std::vector<int16_t> src;     // producing lane inside the window, or -1
+  int64_t n_sets = 0;           // DAG depth of the sweep
+};
+// rows_as = matrix whose OUTER index is the "row" the sweep walks (for SpGS
+// that is the CSC itself, smoother.hpp:101-117).  backward: row order n-1..0.
+// Numerically zero entries do not create dependencies (x + 0*u == x).
+std::string build_lex_schedule(const Sparse& rows_as, bool backward,
+                               int32_t max_width, LexSchedule* out);
+
+// ---- multicolour ordering -----------------------------------------------------
+// Greedy first-fit colouring in row order over the numerically non-zero
+// pattern.  color[i] in [0, n_colors).
+void greedy_coloring(const Sparse& rows_as, std::vector<int32_t>* color,
+                     int32_t* n_colors);
+
+// ---- Grid<double> (grid.hpp) ------------------------------------------------
+Sparse laplacian(int dim, int64_t n);       // CSC (== CSR, symmetric)
+void rhs(int dim, int64_t n, double* b);
+
+}  // namespace amg_hip

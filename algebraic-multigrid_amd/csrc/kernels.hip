@@ -1,0 +1,503 @@
+// =============================================================================
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the V-cycle.
+//
+// All kernels are HBM-bandwidth bound sparse fp64 kernels (~0.17 flop/byte):
+// no MFMA.  Compile with -ffp-contract=off: parity with the reference's
+// arithmetic (separate IEEE multiply/add, true divide) is part of
+// the contract and several kernels are bit-exact against the CPU oracle.
+//
+// K-CSR (csr_stage_kernel)  -- residual / true Jacobi / generic SpMV / rss terms
+//   One 256-thread workgroup owns 256 consecutive rows.  The workgroup's slice
+//   of the CSR column-index and value arrays is contiguous in HBM, so it is
+//   streamed with 16-byte-per-lane coalesced loads into LDS (the per-row
+//   non-zeros are staged, never gathered).  Then one lane per row walks its
+//   entries out of LDS in ascending column order (bit-exact summation order of
+//   Eigen's column-major SpMV, multigrid.hpp:272-274) and gathers x[col]; for
+//   banded stencil matrices consecutive lanes gather consecutive x, i.e. the
+//   gathers coalesce into a few 128-B lines served by L1/L2.  LDS strides of 5
+//   or 9 entries per lane are bank-conflict free for ds_read_b64 / ds_read_b32.
+// K-Restrict / K-ProlongAdd -- matrix-free LinearInterpolator transfers.
+// K-SumSq                   -- wave-shuffle + LDS tree reduction (deterministic).
+// K-GS-lex (gs_lex_window)  -- exact lexicographic Gauss-Seidel, dependency
+//   scheduled (parity mode, latency bound by construction).
+// K-Band   (band_solve)     -- coarsest-level banded LDL^T solve, one wave.
+// =============================================================================
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace amg_hip {
+
+// ------------------------------------------------------------------ K-CSR ----
+constexpr int CSR_BLOCK = 256;
+
+template <int MODE, int K, int U>
+__global__ __launch_bounds__(CSR_BLOCK) void csr_stage_kernel(
+    int64_t n, int64_t nnz, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ col, const double* __restrict__ val,
+    const double* __restrict__ x, const double* __restrict__ f,
+    double* __restrict__ out, double omega, int64_t diag_shift) {
+  constexpr int CAP = CSR_BLOCK * K;  // entries staged per chunk
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* lds_val = reinterpret_cast<double*>(smem);                    // CAP + 4
+  int32_t* lds_col = reinterpret_cast<int32_t*>(smem + (CAP + 4) * 8);  // CAP + 4
+
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * CSR_BLOCK;
+  const int64_t row = r0 + tid;
+  const bool live = row < n;
+  const int64_t rlast = (r0 + CSR_BLOCK < n) ? r0 + CSR_BLOCK : n;
+  const int64_t p0 = rowptr[r0];
+  const int64_t p1 = rowptr[rlast];
+  int64_t rs = 0, re = 0;
+  double fi = 0.0, xi = 0.0;
+  if (live) {
+    rs = rowptr[row];
+    re = rowptr[row + 1];
+    if (MODE != CSR_SPMV) fi = f[row];
+    if (MODE == CSR_JACOBI) xi = x[row + diag_shift];
+  }
+  double acc = (MODE == CSR_RESID) ? fi : 0.0;
+  double diag = 0.0;
+  const int64_t drow = row + diag_shift;
+
+  for (int64_t c0 = p0 & ~(int64_t)3; c0 < p1; c0 += CAP) {
+    const int64_t c1 = (c0 + CAP < p1) ? c0 + CAP : p1;  // chunk = [c0, c1)
+    const int cnt = (int)(c1 - c0);
+    // ---- stage: coalesced 16-B loads HBM -> LDS ----
+#pragma unroll
+    for (int it = 0; it < K / 4 + 1; ++it) {
+      const int i = (it * CSR_BLOCK + tid) * 4;
+      if (i < cnt) {
+        if (c0 + i + 4 <= nnz) {
+          const int4 cc = *reinterpret_cast<const int4*>(col + c0 + i);
+          *reinterpret_cast<int4*>(lds_col + i) = cc;
+        } else {
+          for (int t = 0; t < 4 && c0 + i + t < nnz; ++t) lds_col[i + t] = col[c0 + i + t];
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < K / 2 + 1; ++it) {
+      const int i = (it * CSR_BLOCK + tid) * 2;
+      if (i < cnt) {
+        if (c0 + i + 2 <= nnz) {
+          const double2 vv = *reinterpret_cast<const double2*>(val + c0 + i);
+          *reinterpret_cast<double2*>(lds_val + i) = vv;
+        } else {
+          lds_val[i] = val[c0 + i];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- one lane per row, ascending column order ----
+    int64_t p = rs > c0 ? rs : c0;
+    const int64_t pe = re < c1 ? re : c1;
+    while (p < pe) {
+      int32_t c[U];
+      double v[U], xx[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool ok = p + u < pe;
+        const int o = ok ? (int)(p + u - c0) : (int)(p - c0);
+        c[u] = lds_col[o];
+        v[u] = lds_val[o];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) xx[u] = x[c[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (p + u < pe) {
+          if (MODE == CSR_RESID) {
+            acc -= v[u] * xx[u];
+          } else if (MODE == CSR_JACOBI) {
+            if ((int64_t)c[u] == drow) diag = v[u];
+            else acc += v[u] * xx[u];
+          } else {
+            acc += v[u] * xx[u];
+          }
+        }
+      }
+      p += U;
+    }
+    __syncthreads();
+  }
+  if (live) {
+    if (MODE == CSR_RESID || MODE == CSR_SPMV) {
+      out[row] = acc;
+    } else if (MODE == CSR_JACOBI) {
+      out[row] = (diag == 0.0) ? xi : xi + omega * ((fi - acc) / diag - xi);
+    } else {  // CSR_RSSQ: (b - bhat)^2, common.hpp:24
+      const double d = fi - acc;
+      out[row] = d * d;
+    }
+  }
+}
+
+template <int MODE, int K, int U>
+static hipError_t launch_csr_ku(int64_t n, int64_t nnz, const int32_t* rowptr,
+                                const int32_t* col, const double* val,
+                                const double* x, const double* f, double* out,
+                                double omega, int64_t diag_shift, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  const size_t lds = (size_t)(CSR_BLOCK * K + 4) * 12;
+  const unsigned grid = (unsigned)((n + CSR_BLOCK - 1) / CSR_BLOCK);
+  hipLaunchKernelGGL((csr_stage_kernel<MODE, K, U>), dim3(grid), dim3(CSR_BLOCK), lds,
+                     st, n, nnz, rowptr, col, val, x, f, out, omega, diag_shift);
+  return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_csr_mode(int64_t n, int64_t nnz, int max_block_nnz,
+                                  int max_row_nnz, const int32_t* rowptr,
+                                  const int32_t* col, const double* val,
+                                  const double* x, const double* f, double* out,
+                                  double omega, int64_t diag_shift, hipStream_t st) {
+  // +3: the chunk start is rounded down to a multiple of 4 entries
+  const int need = max_block_nnz + 3;
+  if (need <= CSR_BLOCK * 6 && max_row_nnz <= 8)
+    return launch_csr_ku<MODE, 6, 8>(n, nnz, rowptr, col, val, x, f, out, omega, diag_shift, st);
+  if (need <= CSR_BLOCK * 10 && max_row_nnz <= 12)
+    return launch_csr_ku<MODE, 10, 12>(n, nnz, rowptr, col, val, x, f, out, omega, diag_shift, st);
+  return launch_csr_ku<MODE, 16, 8>(n, nnz, rowptr, col, val, x, f, out, omega, diag_shift, st);
+}
+
+hipError_t launch_csr(int mode, int64_t n, int64_t nnz, int max_block_nnz,
+                      int max_row_nnz, const int32_t* rowptr, const int32_t* col,
+                      const double* val, const double* x, const double* f,
+                      double* out, double omega, int64_t diag_shift, hipStream_t st) {
+  switch (mode) {
+    case CSR_RESID:
+      return launch_csr_mode<CSR_RESID>(n, nnz, max_block_nnz, max_row_nnz, rowptr, col,
+                                        val, x, f, out, omega, diag_shift, st);
+    case CSR_JACOBI:
+      return launch_csr_mode<CSR_JACOBI>(n, nnz, max_block_nnz, max_row_nnz, rowptr, col,
+                                         val, x, f, out, omega, diag_shift, st);
+    case CSR_SPMV:
+      return launch_csr_mode<CSR_SPMV>(n, nnz, max_block_nnz, max_row_nnz, rowptr, col,
+                                       val, x, f, out, omega, diag_shift, st);
+    case CSR_RSSQ:
+      return launch_csr_mode<CSR_RSSQ>(n, nnz, max_block_nnz, max_row_nnz, rowptr, col,
+                                       val, x, f, out, omega, diag_shift, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+// Device-side scan of the row pointer for the two launch parameters above
+// (used by the device-pointer entry points, where the host has no copy).
+__global__ __launch_bounds__(256) void csr_shape_kernel(int64_t n,
+                                                        const int32_t* __restrict__ rowptr,
+                                                        int32_t* __restrict__ out2) {
+  int mb = 0, mr = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = rowptr[i + 1] - rowptr[i];
+    mr = r > mr ? r : mr;
+    if ((i % CSR_BLOCK) == 0) {
+      const int64_t e = i + CSR_BLOCK < n ? i + CSR_BLOCK : n;
+      const int b = rowptr[e] - rowptr[i];
+      mb = b > mb ? b : mb;
+    }
+  }
+  atomicMax(&out2[0], mb);
+  atomicMax(&out2[1], mr);
+}
+hipError_t launch_csr_shape(int64_t n, const int32_t* rowptr, int32_t* out2,
+                            hipStream_t st) {
+  hipError_t e = hipMemsetAsync(out2, 0, 8, st);
+  if (e != hipSuccess) return e;
+  if (n <= 0) return hipSuccess;
+  int64_t g = (n + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(csr_shape_kernel, dim3((unsigned)g), dim3(256), 0, st, n, rowptr, out2);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------- K-Restrict / K-ProlongAdd ---
+// f_H[j] = ((0 + 0.5 r[2j]) + 1.0 r[2j+1]) + 0.5 r[2j+2]   (Eigen column-major
+// scatter order of R*v, interpolator.hpp:64-68 with R = P^T, :132-134).
+__global__ __launch_bounds__(256) void linear_restrict_kernel(
+    int64_t n_h, int64_t n_H, const double* __restrict__ r, double* __restrict__ fH) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_H) return;
+  const int64_t i = 2 * j;
+  double s = 0.0;
+  if (i < n_h) s += 0.5 * r[i];
+  if (i + 1 < n_h) s += 1.0 * r[i + 1];
+  if (i + 2 < n_h) s += 0.5 * r[i + 2];
+  fH[j] = s;
+}
+// u_h[i] = u_h[i] + t[i], t = P u_H: t[2j+1] = 0 + 1.0 u_H[j];
+// t[2j] = (0 + 0.5 u_H[j-1]) + 0.5 u_H[j]; rows past 2 n_H get t = 0
+// (interpolator.hpp:52-56, multigrid.hpp:294-296).
+__global__ __launch_bounds__(256) void linear_prolong_add_kernel(
+    int64_t n_h, int64_t n_H, const double* __restrict__ uH, double* __restrict__ uh) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_h) return;
+  double t = 0.0;
+  const int64_t j = i >> 1;
+  if (i & 1) {
+    if (j < n_H) t += 1.0 * uH[j];
+  } else {
+    if (j >= 1 && j - 1 < n_H) t += 0.5 * uH[j - 1];  // column j-1, row 2(j-1)+2
+    if (j < n_H) t += 0.5 * uH[j];                    // column j,   row 2j
+  }
+  uh[i] = uh[i] + t;
+}
+hipError_t launch_linear_restrict(int64_t n_h, int64_t n_H, const double* r, double* fH,
+                                  hipStream_t st) {
+  if (n_H <= 0) return hipSuccess;
+  hipLaunchKernelGGL(linear_restrict_kernel, dim3((unsigned)((n_H + 255) / 256)),
+                     dim3(256), 0, st, n_h, n_H, r, fH);
+  return hipGetLastError();
+}
+hipError_t launch_linear_prolong_add(int64_t n_h, int64_t n_H, const double* uH,
+                                     double* uh, hipStream_t st) {
+  if (n_h <= 0) return hipSuccess;
+  hipLaunchKernelGGL(linear_prolong_add_kernel, dim3((unsigned)((n_h + 255) / 256)),
+                     dim3(256), 0, st, n_h, n_H, uH, uh);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(int64_t n,
+                                                          const double* __restrict__ x,
+                                                          double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = y[i] + x[i];
+}
+hipError_t launch_add_inplace(int64_t n, const double* x, double* y, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     st, n, x, y);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- K-SumSq ----
+// Deterministic two-stage reduction: grid-stride per-thread sums, wave shuffle
+// tree, LDS across the 4 waves, one partial per block; the last stage is one
+// block over <= 1024 partials.  square=1: sum of x^2, square=0: plain sum.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void sum_kernel(int64_t n, const double* __restrict__ x,
+                                                  double* __restrict__ out, int square) {
+  __shared__ double part[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = x[i];
+    s += square ? v * v : v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = ((part[0] + part[1]) + part[2]) + part[3];
+}
+hipError_t launch_sum(int64_t n, const double* x, double* out, double* scratch, int square,
+                      hipStream_t st) {
+  int64_t g = (n + 255) / 256;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(sum_kernel, dim3((unsigned)g), dim3(256), 0, st, n, x, scratch, square);
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, g, scratch, out, 0);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- K-GS-lex ---
+// Exact lexicographic Gauss-Seidel (smoother.hpp:101-174) under a dependency
+// schedule built on the host (host_setup.cpp: build_lex_schedule).  ONE
+// workgroup walks the level window by window (BLOCK slots per window).  Inside
+// a window every lane first gathers the u values that do not come from this
+// window (old values and values finished by earlier windows), then the window
+// is resolved in `win_depth+1` steps: a lane at dependency depth d sums its
+// row in ascending column order, taking in-window producers from LDS.  Any
+// execution that honours the dependencies and keeps each row's summation order
+// reproduces the sequential sweep bit for bit.
+//   MODE 0: SparseGaussSeidel update  (b - rsum)/diag, unchanged if diag == 0
+//   MODE 1: AMG::Jacobi               (b - sigma)/aii  (aii = 0 if absent)
+//   MODE 2: SOR  uk + omega*((b - s_less - s_greater)/aii - uk)
+template <int BLOCK, int MAXE>
+__global__ __launch_bounds__(BLOCK) void gs_lex_window(
+    int64_t n_slots, int width, const int32_t* __restrict__ slot_row,
+    const int16_t* __restrict__ slot_depth, const int32_t* __restrict__ win_depth,
+    const int32_t* __restrict__ ecol, const double* __restrict__ eval,
+    const int16_t* __restrict__ esrc, const double* __restrict__ b, double* u,
+    int mode, double omega) {
+  __shared__ double pub[BLOCK];
+  const int lane = threadIdx.x;
+  const int64_t n_win = n_slots / BLOCK;
+  for (int64_t w = 0; w < n_win; ++w) {
+    const int64_t slot = w * BLOCK + lane;
+    const int row = slot_row[slot];
+    const int depth = slot_depth[slot];
+    const int wd = win_depth[w];
+    int32_t c[MAXE];
+    int32_t sr[MAXE];
+    double v[MAXE], xg[MAXE];
+    double bi = 0.0, uk = 0.0;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      c[e] = -1;
+      sr[e] = -1;
+      v[e] = 0.0;
+      if (e < width && row >= 0) {
+        const int64_t at = (int64_t)e * n_slots + slot;
+        c[e] = ecol[at];
+        v[e] = eval[at];
+        sr[e] = esrc[at];
+      }
+    }
+    if (row >= 0) {
+      bi = b[row];
+      uk = u[row];
+    }
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e)
+      xg[e] = (c[e] >= 0 && sr[e] < 0) ? u[c[e]] : 0.0;
+    double unew = uk;
+    for (int d = 0; d <= wd; ++d) {
+      if (row >= 0 && depth == d) {
+        double s = 0.0, s2 = 0.0, diag = 0.0;
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) {
+          if (c[e] >= 0) {
+            if (c[e] == row) {
+              diag = v[e];
+            } else {
+              const double xv = (sr[e] >= 0) ? pub[sr[e]] : xg[e];
+              if (mode == 2 && c[e] > row) s2 += v[e] * xv;
+              else s += v[e] * xv;
+            }
+          }
+        }
+        if (mode == 0) unew = (diag == 0.0) ? uk : (bi - s) / diag;
+        else if (mode == 1) unew = (bi - s) / diag;
+        else unew = uk + omega * ((bi - s - s2) / diag - uk);
+        pub[lane] = unew;
+      }
+      __syncthreads();
+    }
+    if (row >= 0) u[row] = unew;
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+template <int BLOCK>
+static hipError_t launch_gs_lex_b(const LexDev& S, const double* b, double* u, int mode,
+                                  double omega, hipStream_t st) {
+  if (S.width <= 8)
+    hipLaunchKernelGGL((gs_lex_window<BLOCK, 8>), dim3(1), dim3(BLOCK), 0, st, S.n_slots,
+                       S.width, S.row, S.depth, S.win_depth, S.col, S.val, S.src, b, u, mode,
+                       omega);
+  else
+    hipLaunchKernelGGL((gs_lex_window<BLOCK, 16>), dim3(1), dim3(BLOCK), 0, st, S.n_slots,
+                       S.width, S.row, S.depth, S.win_depth, S.col, S.val, S.src, b, u, mode,
+                       omega);
+  return hipGetLastError();
+}
+hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, double omega,
+                         hipStream_t st) {
+  if (S.n_slots <= 0) return hipSuccess;
+  if (S.width > 16) return hipErrorInvalidValue;
+  switch (S.block) {
+    case 64: return launch_gs_lex_b<64>(S, b, u, mode, omega, st);
+    case 256: return launch_gs_lex_b<256>(S, b, u, mode, omega, st);
+    case 1024: return launch_gs_lex_b<1024>(S, b, u, mode, omega, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------ K-Band ---
+// x = A^-1 f with A = L D L^T banded (half-bandwidth w <= 63), ONE wave.
+// Lane l keeps the running right-hand side of the rows i == l (mod 64) in a
+// register.  Forward, step k: y_k is complete in lane k&63 -> broadcast by
+// v_readlane, rows k+1..k+w subtract L[k+d,k]*y_k (ascending k per row, the
+// order of a row-oriented substitution); then z = y/D (IEEE divide) and the
+// mirror-image backward pass.  L columns are prefetched CH steps ahead.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+constexpr int BAND_CH = 8;
+__global__ __launch_bounds__(64) void band_solve_kernel(
+    int64_t n, int w, const double* __restrict__ lcol, const double* __restrict__ dg,
+    const double* __restrict__ f, double* __restrict__ x) {
+  const int lane = threadIdx.x;
+  const int wq = w > 0 ? w : 1;
+  // ---- forward: L y = f ----
+  double acc = (lane < n) ? f[lane] : 0.0;
+  for (int64_t k0 = 0; k0 < n; k0 += BAND_CH) {
+    double lc[BAND_CH];
+#pragma unroll
+    for (int i = 0; i < BAND_CH; ++i) {
+      const int64_t k = k0 + i;
+      const int d = (lane - (int)(k & 63)) & 63;
+      lc[i] = (k < n && d >= 1 && d <= w && k + d < n) ? lcol[k * wq + (d - 1)] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < BAND_CH; ++i) {
+      const int64_t k = k0 + i;
+      if (k < n) {
+        const int owner = (int)(k & 63);
+        const double yk = readlane_f64(acc, owner);
+        const int d = (lane - owner) & 63;
+        if (d >= 1 && d <= w && k + d < n) acc -= lc[i] * yk;
+        if (lane == owner) {
+          x[k] = yk;
+          acc = (k + 64 < n) ? f[k + 64] : 0.0;
+        }
+      }
+    }
+  }
+  __threadfence_block();
+  // ---- diagonal: z = y / D ----
+  for (int64_t i = lane; i < n; i += 64) x[i] = x[i] / dg[i];
+  __threadfence_block();
+  // ---- backward: L^T x = z; row i collects k = i+w .. i+1 (descending) ----
+  // lane ownership mirrored: row i lives in lane (n-1-i) & 63
+  {
+    const int64_t i0 = n - 1 - lane;
+    acc = (i0 >= 0) ? x[i0] : 0.0;
+  }
+  for (int64_t t0 = 0; t0 < n; t0 += BAND_CH) {
+    double lc[BAND_CH];
+#pragma unroll
+    for (int i = 0; i < BAND_CH; ++i) {
+      const int64_t t = t0 + i;         // t-th step handles k = n-1-t
+      const int64_t k = n - 1 - t;
+      const int d = (lane - (int)(t & 63)) & 63;  // this lane's row is k-d
+      lc[i] = (t < n && d >= 1 && d <= w && k - d >= 0) ? lcol[(k - d) * wq + (d - 1)] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < BAND_CH; ++i) {
+      const int64_t t = t0 + i;
+      if (t < n) {
+        const int64_t k = n - 1 - t;
+        const int owner = (int)(t & 63);
+        const double xk = readlane_f64(acc, owner);
+        const int d = (lane - owner) & 63;
+        if (d >= 1 && d <= w && k - d >= 0) acc -= lc[i] * xk;
+        if (lane == owner) {
+          const int64_t nxt = k - 64;   // next row owned by this lane
+          const double z = (nxt >= 0) ? x[nxt] : 0.0;
+          x[k] = xk;
+          acc = z;
+        }
+      }
+    }
+  }
+}
+hipError_t launch_band_solve(int64_t n, int w, const double* lcol, const double* dg,
+                             const double* f, double* x, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (w > 63) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(64), 0, st, n, w, lcol, dg, f, x);
+  return hipGetLastError();
+}
+
+}  // namespace amg_hip

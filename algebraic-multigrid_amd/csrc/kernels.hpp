@@ -1,0 +1,50 @@
+// Launchers of the gfx950 kernels (kernels.hip).  Device pointers only.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace amg_hip {
+
+enum CsrMode {
+  CSR_RESID = 0,   // out = f - A x   (ascending column order per row)
+  CSR_JACOBI = 1,  // out = x_i + omega*((f_i - sum_{j!=i} a_ij x_j)/a_ii - x_i)
+  CSR_SPMV = 2,    // out = A x
+  CSR_RSSQ = 3     // out_i = (f_i - (A x)_i)^2
+};
+
+// max_block_nnz: max entries in any 256-row block; max_row_nnz: longest row.
+hipError_t launch_csr(int mode, int64_t n, int64_t nnz, int max_block_nnz,
+                      int max_row_nnz, const int32_t* rowptr, const int32_t* col,
+                      const double* val, const double* x, const double* f,
+                      double* out, double omega, int64_t diag_shift, hipStream_t st);
+// out2[0] = max_block_nnz, out2[1] = max_row_nnz (device int32[2])
+hipError_t launch_csr_shape(int64_t n, const int32_t* rowptr, int32_t* out2,
+                            hipStream_t st);
+
+hipError_t launch_linear_restrict(int64_t n_h, int64_t n_H, const double* r, double* fH,
+                                  hipStream_t st);
+hipError_t launch_linear_prolong_add(int64_t n_h, int64_t n_H, const double* uH,
+                                     double* uh, hipStream_t st);
+hipError_t launch_add_inplace(int64_t n, const double* x, double* y, hipStream_t st);
+// *out = sum x_i (square=0) or sum x_i^2 (square=1); scratch: 1024 doubles
+hipError_t launch_sum(int64_t n, const double* x, double* out, double* scratch, int square,
+                      hipStream_t st);
+
+struct LexDev {  // device copy of a LexSchedule
+  int32_t block = 0, width = 0;
+  int64_t n_slots = 0;
+  const int32_t* row = nullptr;
+  const int16_t* depth = nullptr;
+  const int32_t* win_depth = nullptr;
+  const int32_t* col = nullptr;
+  const double* val = nullptr;
+  const int16_t* src = nullptr;
+};
+// mode 0 SpGS, 1 reference "Jacobi" (forward GS), 2 SOR
+hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, double omega,
+                         hipStream_t st);
+
+hipError_t launch_band_solve(int64_t n, int w, const double* lcol, const double* dg,
+                             const double* f, double* x, hipStream_t st);
+
+}  // namespace amg_hip

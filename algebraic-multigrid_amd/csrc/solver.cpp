@@ -1,0 +1,1003 @@
+// =============================================================================
+// solver.cpp -- the C ABI of include/amg_hip.h: solver handle, V-cycle
+// orchestration on one HIP stream (replayed as a hipGraph), stand-alone plug-in
+// operations and device-pointer launchers.  No CPU fallback anywhere: every
+// compute entry point needs a HIP device and fails with AMG_HIP_EHIP otherwise.
+// =============================================================================
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/amg_hip.h"
+#include "host_setup.hpp"
+#include "kernels.hpp"
+
+using namespace amg_hip;
+
+namespace {
+
+thread_local std::string g_err;
+
+amg_hip_status fail(amg_hip_status st, const std::string& msg) {
+  g_err = msg;
+  return st;
+}
+
+#define HIP_TRY(expr)                                                          \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess)                                                      \
+      return fail(_e == hipErrorOutOfMemory ? AMG_HIP_ENOMEM : AMG_HIP_EHIP,   \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));          \
+  } while (0)
+
+int host_threads() {
+  unsigned h = std::thread::hardware_concurrency();
+  if (h == 0) h = 1;
+  return (int)std::min(h, 16u);
+}
+
+// ---- device buffers ---------------------------------------------------------
+struct DevMem {  // owns one hipMalloc allocation
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevMem() = default;
+  DevMem(const DevMem&) = delete;
+  DevMem& operator=(const DevMem&) = delete;
+  DevMem(DevMem&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevMem& operator=(DevMem&& o) noexcept {
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  ~DevMem() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  // 64 bytes of slack so that 16-byte vector loads of a tail never leave the
+  // allocation
+  hipError_t alloc(size_t n) {
+    release();
+    bytes = n;
+    return hipMalloc(&p, n + 64);
+  }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+template <class T>
+hipError_t upload(DevMem& m, const T* src, size_t count) {
+  hipError_t e = m.alloc(count * sizeof(T));
+  if (e != hipSuccess) return e;
+  if (count == 0) return hipSuccess;
+  return hipMemcpy(m.p, src, count * sizeof(T), hipMemcpyHostToDevice);
+}
+
+struct DevCsr {  // row-major view on the device
+  int64_t n_rows = 0, n_cols = 0, nnz = 0;
+  int max_block_nnz = 0, max_row_nnz = 0;
+  DevMem ptr, idx, val;
+  const int32_t* rowptr() const { return ptr.as<int32_t>(); }
+  const int32_t* col() const { return idx.as<int32_t>(); }
+  const double* v() const { return val.as<double>(); }
+};
+
+void csr_shape(const Sparse& M, int* max_block, int* max_row) {
+  int mb = 0, mr = 0;
+  for (int64_t r = 0; r < M.n_outer; ++r) mr = std::max(mr, M.ptr[r + 1] - M.ptr[r]);
+  for (int64_t r = 0; r < M.n_outer; r += 256) {
+    const int64_t e = std::min<int64_t>(r + 256, M.n_outer);
+    mb = std::max(mb, M.ptr[e] - M.ptr[r]);
+  }
+  *max_block = mb;
+  *max_row = mr;
+}
+
+hipError_t upload_csr(const Sparse& M, DevCsr* D) {
+  D->n_rows = M.n_outer;
+  D->n_cols = M.n_inner;
+  D->nnz = M.nnz();
+  csr_shape(M, &D->max_block_nnz, &D->max_row_nnz);
+  hipError_t e;
+  if ((e = upload(D->ptr, M.ptr.data(), M.ptr.size())) != hipSuccess) return e;
+  if ((e = upload(D->idx, M.idx.data(), M.idx.size())) != hipSuccess) return e;
+  return upload(D->val, M.val.data(), M.val.size());
+}
+
+struct LexOnDev {
+  LexDev d;
+  DevMem row, depth, win_depth, col, val, src;
+  int64_t n_sets = 0;
+};
+
+hipError_t upload_lex(const LexSchedule& S, LexOnDev* L) {
+  hipError_t e;
+  if ((e = upload(L->row, S.row.data(), S.row.size())) != hipSuccess) return e;
+  if ((e = upload(L->depth, S.depth.data(), S.depth.size())) != hipSuccess) return e;
+  if ((e = upload(L->win_depth, S.win_depth.data(), S.win_depth.size())) != hipSuccess) return e;
+  if ((e = upload(L->col, S.col.data(), S.col.size())) != hipSuccess) return e;
+  if ((e = upload(L->val, S.val.data(), S.val.size())) != hipSuccess) return e;
+  if ((e = upload(L->src, S.src.data(), S.src.size())) != hipSuccess) return e;
+  L->d.block = S.block;
+  L->d.width = S.width;
+  L->d.n_slots = S.n_slots;
+  L->d.row = L->row.as<int32_t>();
+  L->d.depth = L->depth.as<int16_t>();
+  L->d.win_depth = L->win_depth.as<int32_t>();
+  L->d.col = L->col.as<int32_t>();
+  L->d.val = L->val.as<double>();
+  L->d.src = L->src.as<int16_t>();
+  L->n_sets = S.n_sets;
+  return hipSuccess;
+}
+
+struct ColorSet {  // rows of one colour, for the multicolour smoother
+  int64_t count = 0;
+  DevMem rows;  // int32 row ids ascending
+};
+
+struct Level {
+  int64_t n = 0;
+  Sparse A_csc;            // host copy, what get_coefficient_matrix returns
+  DevCsr A_rows;           // CSR(A): residual, AMG::Jacobi, SOR
+  DevCsr A_cols_own;       // CSC arrays walked as rows (SpGS & build-side
+  bool symmetric = false;  //   smoothers); aliases A_rows when bitwise equal
+  const DevCsr& A_cols() const { return symmetric ? A_rows : A_cols_own; }
+  DevMem u, f, r, tmp;
+  // transfers to level+1 (absent on the coarsest level)
+  Sparse P_csc, R_csc;
+  bool linear = false;
+  DevCsr P_rows, R_rows;   // CSR(P), CSR(R)
+  // exact lexicographic schedules
+  std::unique_ptr<LexOnDev> lex_fwd, lex_bwd;
+  // multicolour
+  std::vector<int32_t> color;
+  int32_t n_colors = 0;
+  std::vector<ColorSet> color_sets;
+};
+
+}  // namespace
+
+struct amg_hip_solver {
+  amg_hip_options opt;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<Level> lv;
+  // coarsest level factor
+  int64_t band_n = 0, band_w = 0;
+  DevMem band_l, band_d;
+  DevMem scratch;   // 1024 doubles + 1 result
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  bool graph_ready = false;
+  double cycle_bytes = 0, fine_sweep_bytes = 0;
+
+  ~amg_hip_solver() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+// ---- smoother on one level --------------------------------------------------
+amg_hip_status enqueue_multicolor(amg_hip_solver* s, Level& L, hipStream_t st);
+
+amg_hip_status enqueue_smooth(amg_hip_solver* s, int l) {
+  Level& L = s->lv[l];
+  hipStream_t st = s->stream;
+  const int iters = s->opt.smoother_iters;
+  switch (s->opt.smoother) {
+    case AMG_HIP_SM_SPGS:
+      for (int it = 0; it < iters; ++it) {
+        HIP_TRY(launch_gs_lex(L.lex_fwd->d, L.f.as<double>(), L.u.as<double>(), 0, 1.0, st));
+        HIP_TRY(launch_gs_lex(L.lex_bwd->d, L.f.as<double>(), L.u.as<double>(), 0, 1.0, st));
+      }
+      return AMG_HIP_OK;
+    case AMG_HIP_SM_REF_JACOBI:
+    case AMG_HIP_SM_SOR: {
+      const int mode = s->opt.smoother == AMG_HIP_SM_SOR ? 2 : 1;
+      for (int it = 0; it < iters; ++it)
+        HIP_TRY(launch_gs_lex(L.lex_fwd->d, L.f.as<double>(), L.u.as<double>(), mode,
+                              s->opt.omega, st));
+      return AMG_HIP_OK;
+    }
+    case AMG_HIP_SM_JACOBI: {
+      const DevCsr& A = L.A_cols();
+      double* a = L.u.as<double>();
+      double* b = L.tmp.as<double>();
+      for (int it = 0; it < iters; ++it) {
+        HIP_TRY(launch_csr(CSR_JACOBI, A.n_rows, A.nnz, A.max_block_nnz, A.max_row_nnz,
+                           A.rowptr(), A.col(), A.v(), a, L.f.as<double>(), b,
+                           s->opt.omega, 0, st));
+        std::swap(a, b);
+      }
+      if (iters & 1)  // result sits in tmp: bring it home (keeps the graph static)
+        HIP_TRY(hipMemcpyAsync(L.u.p, L.tmp.p, sizeof(double) * L.n,
+                               hipMemcpyDeviceToDevice, st));
+      return AMG_HIP_OK;
+    }
+    case AMG_HIP_SM_MULTICOLOR_GS:
+      for (int it = 0; it < iters; ++it) {
+        amg_hip_status r = enqueue_multicolor(s, L, st);
+        if (r != AMG_HIP_OK) return r;
+      }
+      return AMG_HIP_OK;
+  }
+  return fail(AMG_HIP_EINVAL, "unknown smoother kind");
+}
+
+amg_hip_status enqueue_multicolor(amg_hip_solver*, Level&, hipStream_t) {
+  return fail(AMG_HIP_EUNSUPPORTED, "multicolour Gauss-Seidel: not built yet");
+}
+
+amg_hip_status enqueue_residual(amg_hip_solver* s, int l) {
+  Level& L = s->lv[l];
+  const DevCsr& A = L.A_rows;
+  HIP_TRY(launch_csr(CSR_RESID, A.n_rows, A.nnz, A.max_block_nnz, A.max_row_nnz, A.rowptr(),
+                     A.col(), A.v(), L.u.as<double>(), L.f.as<double>(), L.r.as<double>(),
+                     1.0, 0, s->stream));
+  return AMG_HIP_OK;
+}
+
+// multigrid.hpp:263-305
+amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
+  const int nl = (int)s->lv.size();
+  hipStream_t st = s->stream;
+  for (int l = 0; l < nl; ++l) {
+    amg_hip_status r = enqueue_smooth(s, l);                       // :268
+    if (r != AMG_HIP_OK) return r;
+    if ((r = enqueue_residual(s, l)) != AMG_HIP_OK) return r;      // :272-274
+    if (l + 1 != nl) {
+      Level& L = s->lv[l];
+      Level& C = s->lv[l + 1];
+      HIP_TRY(hipMemsetAsync(C.u.p, 0, sizeof(double) * C.n, st)); // :278
+      if (L.linear && s->opt.stencil_transfers) {                  // :281-282
+        HIP_TRY(launch_linear_restrict(L.n, C.n, L.r.as<double>(), C.f.as<double>(), st));
+      } else {
+        const DevCsr& R = L.R_rows;
+        HIP_TRY(launch_csr(CSR_SPMV, R.n_rows, R.nnz, R.max_block_nnz, R.max_row_nnz,
+                           R.rowptr(), R.col(), R.v(), L.r.as<double>(), nullptr,
+                           C.f.as<double>(), 1.0, 0, st));
+      }
+    }
+  }
+  {                                                                // :287-288
+    Level& C = s->lv[nl - 1];
+    HIP_TRY(launch_band_solve(s->band_n, (int)s->band_w, s->band_l.as<double>(),
+                              s->band_d.as<double>(), C.f.as<double>(), C.u.as<double>(), st));
+  }
+  for (int l = nl - 2; l >= 0; --l) {                              // :291
+    Level& L = s->lv[l];
+    Level& C = s->lv[l + 1];
+    if (L.linear && s->opt.stencil_transfers) {                    // :294-296
+      HIP_TRY(launch_linear_prolong_add(L.n, C.n, C.u.as<double>(), L.u.as<double>(), st));
+    } else {
+      const DevCsr& P = L.P_rows;
+      HIP_TRY(launch_csr(CSR_SPMV, P.n_rows, P.nnz, P.max_block_nnz, P.max_row_nnz,
+                         P.rowptr(), P.col(), P.v(), C.u.as<double>(), nullptr,
+                         L.tmp.as<double>(), 1.0, 0, st));
+      HIP_TRY(launch_add_inplace(L.n, L.tmp.as<double>(), L.u.as<double>(), st));
+    }
+    amg_hip_status r = enqueue_smooth(s, l);                       // :300
+    if (r != AMG_HIP_OK) return r;
+  }
+  return AMG_HIP_OK;
+}
+
+amg_hip_status ensure_graph(amg_hip_solver* s) {
+  if (s->graph_ready) return AMG_HIP_OK;
+  HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+  amg_hip_status r = enqueue_vcycle(s);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(s->stream, &g);
+  if (r != AMG_HIP_OK) {
+    if (g) (void)hipGraphDestroy(g);
+    return r;
+  }
+  if (e != hipSuccess) return fail(AMG_HIP_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+  s->graph = g;
+  HIP_TRY(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
+  s->graph_ready = true;
+  return AMG_HIP_OK;
+}
+
+amg_hip_status set_device(const amg_hip_solver* s) {
+  HIP_TRY(hipSetDevice(s->device));
+  return AMG_HIP_OK;
+}
+
+// ---- bytes model ----------------------------------------------
+void compute_bytes(amg_hip_solver* s) {
+  const int nl = (int)s->lv.size();
+  double total = 0;
+  const int iters = s->opt.smoother_iters;
+  int sweeps_per_smooth = iters;
+  if (s->opt.smoother == AMG_HIP_SM_SPGS || s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS)
+    sweeps_per_smooth = 2 * iters;
+  for (int l = 0; l < nl; ++l) {
+    const Level& L = s->lv[l];
+    const double sweep = 12.0 * (double)L.A_csc.nnz() + 28.0 * (double)L.n;
+    if (l == 0) s->fine_sweep_bytes = sweep;
+    // pre-smooth + residual on every level; post-smooth on all but the coarsest
+    total += sweep * (sweeps_per_smooth + 1);
+    if (l + 1 != nl) {
+      total += sweep * sweeps_per_smooth;
+      const double nH = (double)s->lv[l + 1].n, nh = (double)L.n;
+      total += 8.0 * nH;                                   // zero
+      total += 12.0 * 3 * nH + 4 * nH + 8 * nh + 8 * nH;   // restrict (CSR R)
+      total += 12.0 * 3 * nH + 4 * nh + 8 * nH + 16 * nh;  // prolong + add (CSR P)
+    }
+  }
+  s->cycle_bytes = total;
+}
+
+// ---- setup --------------------------------------------------------------------
+amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* rowind,
+                            const double* val, const double* b, int32_t n_levels,
+                            const int32_t* const* Pc, const int32_t* const* Pr,
+                            const double* const* Pv, const int32_t* const* Rc,
+                            const int32_t* const* Rr, const double* const* Rv,
+                            const amg_hip_options* opts, amg_hip_solver** out) {
+  if (!out) return fail(AMG_HIP_EINVAL, "out handle pointer is null");
+  *out = nullptr;
+  if (!colptr || !rowind || !val || !b) return fail(AMG_HIP_EINVAL, "null input array");
+  if (n <= 0) return fail(AMG_HIP_EINVAL, "`A` must have at least one degree of freedom");
+  if (n_levels < 1) return fail(AMG_HIP_EINVAL, "`n_levels` must be at least 1");
+  std::unique_ptr<amg_hip_solver> s(new amg_hip_solver);
+  if (opts) s->opt = *opts;
+  else amg_hip_default_options(&s->opt);
+  if (s->opt.smoother < 0 || s->opt.smoother > AMG_HIP_SM_MULTICOLOR_GS)
+    return fail(AMG_HIP_EINVAL, "unknown smoother kind");
+  if (s->opt.smoother_iters < 0) return fail(AMG_HIP_EINVAL, "`smoother_iters` must be >= 0");
+  if (s->opt.smoother == AMG_HIP_SM_SOR && (s->opt.omega > 2 || s->opt.omega < 0))
+    return fail(AMG_HIP_EINVAL, "`omega` must be in [0, 2] but got omega=" +
+                                    std::to_string(s->opt.omega) + "\n");  // smoother.hpp:286-293
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(AMG_HIP_EHIP, "no HIP device available (this library has no CPU fallback)");
+  if (s->opt.device >= 0) {
+    if (s->opt.device >= ndev) return fail(AMG_HIP_EINVAL, "device ordinal out of range");
+    s->device = s->opt.device;
+  } else {
+    HIP_TRY(hipGetDevice(&s->device));
+  }
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+
+  const int nt = host_threads();
+  s->lv.resize(n_levels);
+  {
+    Level& L0 = s->lv[0];
+    L0.n = n;
+    L0.A_csc = from_raw(n, n, colptr, rowind, val);
+    std::string v = validate(L0.A_csc, "A");
+    if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
+  }
+  // ---- hierarchy (multigrid.hpp:211-237) ----
+  Sparse A_r = transpose(s->lv[0].A_csc);  // CSR(A_0)
+  for (int l = 0; l < n_levels; ++l) {
+    Level& L = s->lv[l];
+    L.symmetric = same_arrays(A_r, L.A_csc);
+    HIP_TRY(upload_csr(A_r, &L.A_rows));
+    if (!L.symmetric) HIP_TRY(upload_csr(L.A_csc, &L.A_cols_own));
+    HIP_TRY(L.u.alloc(sizeof(double) * L.n));
+    HIP_TRY(L.f.alloc(sizeof(double) * L.n));
+    HIP_TRY(L.r.alloc(sizeof(double) * L.n));
+    HIP_TRY(L.tmp.alloc(sizeof(double) * L.n));
+    HIP_TRY(hipMemset(L.u.p, 0, sizeof(double) * L.n));
+    HIP_TRY(hipMemset(L.f.p, 0, sizeof(double) * L.n));
+    HIP_TRY(hipMemset(L.r.p, 0, sizeof(double) * L.n));
+    // smoother-specific structures
+    if (s->opt.smoother == AMG_HIP_SM_SPGS) {
+      LexSchedule F, B;
+      std::string e = build_lex_schedule(L.A_csc, false, 16, &F);
+      if (e.empty()) e = build_lex_schedule(L.A_csc, true, 16, &B);
+      if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
+      L.lex_fwd.reset(new LexOnDev);
+      L.lex_bwd.reset(new LexOnDev);
+      HIP_TRY(upload_lex(F, L.lex_fwd.get()));
+      HIP_TRY(upload_lex(B, L.lex_bwd.get()));
+    } else if (s->opt.smoother == AMG_HIP_SM_REF_JACOBI || s->opt.smoother == AMG_HIP_SM_SOR) {
+      LexSchedule F;  // these two address A by ROW (A.coeff(i,j), smoother.hpp:251,351)
+      std::string e = build_lex_schedule(A_r, false, 16, &F);
+      if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
+      L.lex_fwd.reset(new LexOnDev);
+      HIP_TRY(upload_lex(F, L.lex_fwd.get()));
+    } else if (s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS) {
+      greedy_coloring(L.A_csc, &L.color, &L.n_colors);
+    }
+    if (l + 1 == n_levels) break;
+    // ---- transfer operators for level l -> l+1 ----
+    const int64_t n_h = L.n;
+    const int64_t n_H = coarse_dofs(n_h);  // multigrid.hpp:214
+    if (n_H < 1)
+      return fail(AMG_HIP_EINVAL, "level " + std::to_string(l + 1) +
+                                      " would have no degrees of freedom; reduce `n_levels`");
+    if (Pc) {
+      L.P_csc = from_raw(n_H, n_h, Pc[l], Pr[l], Pv[l]);
+      L.R_csc = from_raw(n_h, n_H, Rc[l], Rr[l], Rv[l]);
+      std::string v = validate(L.P_csc, "P");
+      if (v.empty()) v = validate(L.R_csc, "R");
+      if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
+      L.linear = is_linear_P(L.P_csc, n_h, n_H) && same_arrays(transpose(L.P_csc), L.R_csc);
+    } else {
+      L.P_csc = linear_P(n_h, n_H);          // interpolator.hpp:106-129
+      L.R_csc = transpose(L.P_csc);          // :132-134
+      L.linear = true;
+    }
+    Sparse P_r = transpose(L.P_csc);  // CSR(P)
+    Sparse R_r = transpose(L.R_csc);  // CSR(R)
+    HIP_TRY(upload_csr(P_r, &L.P_rows));
+    HIP_TRY(upload_csr(R_r, &L.R_rows));
+    // Galerkin (multigrid.hpp:219-223), row-major, Eigen's summation order
+    Sparse AH_r = galerkin_csr(R_r, A_r, P_r, nt);
+    Level& C = s->lv[l + 1];
+    C.n = n_H;
+    C.A_csc = transpose(AH_r);
+    A_r.ptr.swap(AH_r.ptr);
+    A_r.idx.swap(AH_r.idx);
+    A_r.val.swap(AH_r.val);
+    A_r.n_outer = A_r.n_inner = n_H;
+  }
+  // rhs / initial state (multigrid.hpp:196-204)
+  HIP_TRY(hipMemcpy(s->lv[0].f.p, b, sizeof(double) * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->lv[0].r.p, b, sizeof(double) * n, hipMemcpyHostToDevice));  // b - A*0
+  // ---- coarsest factor (multigrid.hpp:240-243) ----
+  {
+    BandFactor F;
+    std::string e = band_factor(s->lv[n_levels - 1].A_csc, (size_t)8 << 30, &F);
+    if (!e.empty()) return fail(AMG_HIP_EINVAL, e);
+    if (F.w > 63)
+      return fail(AMG_HIP_EUNSUPPORTED,
+                  "coarsest operator has half-bandwidth " + std::to_string(F.w) +
+                      " > 63 (device band solve limit); use more levels");
+    s->band_n = F.n;
+    s->band_w = F.w;
+    HIP_TRY(upload(s->band_l, F.lcol.data(), F.lcol.size()));
+    HIP_TRY(upload(s->band_d, F.d.data(), F.d.size()));
+  }
+  HIP_TRY(s->scratch.alloc(sizeof(double) * 1100));
+  compute_bytes(s.get());
+  HIP_TRY(hipDeviceSynchronize());
+  *out = s.release();
+  return AMG_HIP_OK;
+}
+
+// ---- helpers for the stand-alone host-array entry points ---------------------
+struct Scoped {
+  hipStream_t st = nullptr;
+  ~Scoped() { if (st) (void)hipStreamDestroy(st); }
+};
+
+amg_hip_status need_device() {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(AMG_HIP_EHIP, "no HIP device available (this library has no CPU fallback)");
+  return AMG_HIP_OK;
+}
+
+}  // namespace
+
+// =============================================================================
+extern "C" {
+
+const char* amg_hip_last_error(void) { return g_err.c_str(); }
+
+void amg_hip_default_options(amg_hip_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->smoother = AMG_HIP_SM_SPGS;
+  o->smoother_iters = 1;
+  o->omega = 1.0;
+  o->device = -1;
+  o->use_graph = 1;
+  o->stencil_transfers = 1;
+}
+
+int amg_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+amg_hip_status amg_hip_create(int64_t n, const int32_t* colptr, const int32_t* rowind,
+                              const double* val, const double* b, int32_t n_levels,
+                              const amg_hip_options* opts, amg_hip_solver** out) {
+  return build_solver(n, colptr, rowind, val, b, n_levels, nullptr, nullptr, nullptr, nullptr,
+                      nullptr, nullptr, opts, out);
+}
+
+amg_hip_status amg_hip_create_custom(int64_t n, const int32_t* colptr, const int32_t* rowind,
+                                     const double* val, const double* b, int32_t n_levels,
+                                     const int32_t* const* P_colptr,
+                                     const int32_t* const* P_rowind, const double* const* P_val,
+                                     const int32_t* const* R_colptr,
+                                     const int32_t* const* R_rowind, const double* const* R_val,
+                                     const amg_hip_options* opts, amg_hip_solver** out) {
+  if (n_levels > 1 && (!P_colptr || !P_rowind || !P_val || !R_colptr || !R_rowind || !R_val))
+    return fail(AMG_HIP_EINVAL, "custom transfer operator arrays are null");
+  return build_solver(n, colptr, rowind, val, b, n_levels, P_colptr, P_rowind, P_val, R_colptr,
+                      R_rowind, R_val, opts, out);
+}
+
+void amg_hip_destroy(amg_hip_solver* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  delete s;
+}
+
+amg_hip_status amg_hip_vcycles(amg_hip_solver* s, int32_t n) {
+  if (!s) return fail(AMG_HIP_EINVAL, "null solver");
+  amg_hip_status r = set_device(s);
+  if (r != AMG_HIP_OK) return r;
+  if (s->opt.use_graph) {
+    if ((r = ensure_graph(s)) != AMG_HIP_OK) return r;
+    for (int i = 0; i < n; ++i) HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
+  } else {
+    for (int i = 0; i < n; ++i)
+      if ((r = enqueue_vcycle(s)) != AMG_HIP_OK) return r;
+  }
+  return AMG_HIP_OK;
+}
+amg_hip_status amg_hip_vcycle(amg_hip_solver* s) { return amg_hip_vcycles(s, 1); }
+
+amg_hip_status amg_hip_sync(amg_hip_solver* s) {
+  if (!s) return fail(AMG_HIP_EINVAL, "null solver");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_rss(amg_hip_solver* s, double* out) {
+  if (!s || !out) return fail(AMG_HIP_EINVAL, "null argument");
+  amg_hip_status r = set_device(s);
+  if (r != AMG_HIP_OK) return r;
+  Level& L = s->lv[0];
+  const DevCsr& A = L.A_rows;
+  HIP_TRY(launch_csr(CSR_RSSQ, A.n_rows, A.nnz, A.max_block_nnz, A.max_row_nnz, A.rowptr(),
+                     A.col(), A.v(), L.u.as<double>(), L.f.as<double>(), L.tmp.as<double>(),
+                     1.0, 0, s->stream));
+  double* sc = s->scratch.as<double>();
+  HIP_TRY(launch_sum(L.n, L.tmp.as<double>(), sc + 1024, sc, 0, s->stream));
+  HIP_TRY(hipMemcpyAsync(out, sc + 1024, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_solve(amg_hip_solver* s, double tol, int64_t every, int64_t n_iters,
+                             int64_t* iters, double* last_rss, int32_t* converged) {
+  if (!s) return fail(AMG_HIP_EINVAL, "null solver");
+  if (every > n_iters)  // multigrid.hpp:165-171
+    return fail(AMG_HIP_EINVAL, "`compute_error_every_n_iters` must be leq to `n_iters`, got " +
+                                    std::to_string(every) + " and " + std::to_string(n_iters));
+  if (every <= 0) return fail(AMG_HIP_EINVAL, "`compute_error_every_n_iters` must be positive");
+  int64_t iter = 0;
+  double error = 100;  // multigrid.hpp:313
+  while (iter < n_iters && error > tol) {
+    amg_hip_status r = amg_hip_vcycles(s, 1);
+    if (r != AMG_HIP_OK) return r;
+    iter += 1;
+    if ((iter % every) == 0) {
+      if ((r = amg_hip_rss(s, &error)) != AMG_HIP_OK) return r;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (iters) *iters = iter;
+  if (last_rss) *last_rss = error;
+  if (converged) *converged = error <= tol;
+  return AMG_HIP_OK;
+}
+
+int32_t amg_hip_n_levels(const amg_hip_solver* s) { return s ? (int32_t)s->lv.size() : 0; }
+int64_t amg_hip_get_n_dofs(const amg_hip_solver* s, int32_t level) {
+  if (!s || level < 0 || level >= (int32_t)s->lv.size()) return -1;
+  return s->lv[level].n;
+}
+int64_t amg_hip_get_level_nnz(const amg_hip_solver* s, int32_t level) {
+  if (!s || level < 0 || level >= (int32_t)s->lv.size()) return -1;
+  return s->lv[level].A_csc.nnz();
+}
+amg_hip_status amg_hip_get_level_matrix(const amg_hip_solver* s, int32_t level,
+                                        int32_t* colptr, int32_t* rowind, double* val) {
+  if (!s || level < 0 || level >= (int32_t)s->lv.size())
+    return fail(AMG_HIP_EINVAL, "level out of range");
+  const Sparse& A = s->lv[level].A_csc;
+  if (colptr) std::memcpy(colptr, A.ptr.data(), sizeof(int32_t) * A.ptr.size());
+  if (rowind) std::memcpy(rowind, A.idx.data(), sizeof(int32_t) * A.idx.size());
+  if (val) std::memcpy(val, A.val.data(), sizeof(double) * A.val.size());
+  return AMG_HIP_OK;
+}
+int64_t amg_hip_get_transfer_nnz(const amg_hip_solver* s, int32_t level, int32_t which) {
+  if (!s || level < 0 || level + 1 >= (int32_t)s->lv.size()) return -1;
+  return (which ? s->lv[level].R_csc : s->lv[level].P_csc).nnz();
+}
+amg_hip_status amg_hip_get_transfer(const amg_hip_solver* s, int32_t level, int32_t which,
+                                    int32_t* colptr, int32_t* rowind, double* val) {
+  if (!s || level < 0 || level + 1 >= (int32_t)s->lv.size())
+    return fail(AMG_HIP_EINVAL, "level out of range");
+  const Sparse& M = which ? s->lv[level].R_csc : s->lv[level].P_csc;
+  if (colptr) std::memcpy(colptr, M.ptr.data(), sizeof(int32_t) * M.ptr.size());
+  if (rowind) std::memcpy(rowind, M.idx.data(), sizeof(int32_t) * M.idx.size());
+  if (val) std::memcpy(val, M.val.data(), sizeof(double) * M.val.size());
+  return AMG_HIP_OK;
+}
+
+static DevMem* pick_vec(amg_hip_solver* s, int32_t level, int32_t which) {
+  if (!s || level < 0 || level >= (int32_t)s->lv.size()) return nullptr;
+  Level& L = s->lv[level];
+  return which == 0 ? &L.u : (which == 1 ? &L.f : (which == 2 ? &L.r : nullptr));
+}
+amg_hip_status amg_hip_get_vec(amg_hip_solver* s, int32_t level, int32_t which, double* out) {
+  DevMem* m = pick_vec(s, level, which);
+  if (!m || !out) return fail(AMG_HIP_EINVAL, "bad level / vector selector");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(out, m->p, sizeof(double) * s->lv[level].n, hipMemcpyDeviceToHost));
+  return AMG_HIP_OK;
+}
+amg_hip_status amg_hip_set_vec(amg_hip_solver* s, int32_t level, int32_t which,
+                               const double* in) {
+  DevMem* m = pick_vec(s, level, which);
+  if (!m || !in) return fail(AMG_HIP_EINVAL, "bad level / vector selector");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(m->p, in, sizeof(double) * s->lv[level].n, hipMemcpyHostToDevice));
+  return AMG_HIP_OK;
+}
+int64_t amg_hip_coarse_halfbw(const amg_hip_solver* s) { return s ? s->band_w : -1; }
+
+amg_hip_status amg_hip_get_colors(const amg_hip_solver* s, int32_t level, int32_t* color,
+                                  int32_t* n_colors) {
+  if (!s || level < 0 || level >= (int32_t)s->lv.size())
+    return fail(AMG_HIP_EINVAL, "level out of range");
+  const Level& L = s->lv[level];
+  if (L.color.empty()) return fail(AMG_HIP_EINVAL, "solver was not built with the multicolour smoother");
+  if (color) std::memcpy(color, L.color.data(), sizeof(int32_t) * L.color.size());
+  if (n_colors) *n_colors = L.n_colors;
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_cycle_bytes(const amg_hip_solver* s, double* cycle_bytes,
+                                   double* fine_sweep_bytes) {
+  if (!s) return fail(AMG_HIP_EINVAL, "null solver");
+  if (cycle_bytes) *cycle_bytes = s->cycle_bytes;
+  if (fine_sweep_bytes) *fine_sweep_bytes = s->fine_sweep_bytes;
+  return AMG_HIP_OK;
+}
+
+// ---- stand-alone operations on host arrays -------------------------------------
+amg_hip_status amg_hip_residual(int64_t n, const int32_t* colptr, const int32_t* rowind,
+                                const double* val, const double* u, const double* f,
+                                double* r) {
+  amg_hip_status st = need_device();
+  if (st != AMG_HIP_OK) return st;
+  if (n <= 0 || !colptr || !rowind || !val || !u || !f || !r)
+    return fail(AMG_HIP_EINVAL, "bad argument");
+  Sparse A = from_raw(n, n, colptr, rowind, val);
+  std::string v = validate(A, "A");
+  if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
+  Sparse Ar = transpose(A);
+  DevCsr D;
+  DevMem du, df, dr;
+  HIP_TRY(upload_csr(Ar, &D));
+  HIP_TRY(upload(du, u, (size_t)n));
+  HIP_TRY(upload(df, f, (size_t)n));
+  HIP_TRY(dr.alloc(sizeof(double) * n));
+  HIP_TRY(launch_csr(CSR_RESID, n, D.nnz, D.max_block_nnz, D.max_row_nnz, D.rowptr(), D.col(),
+                     D.v(), du.as<double>(), df.as<double>(), dr.as<double>(), 1.0, 0, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(r, dr.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_spmv(int64_t rows, int64_t cols, const int32_t* colptr,
+                            const int32_t* rowind, const double* val, const double* v,
+                            double* out) {
+  amg_hip_status st = need_device();
+  if (st != AMG_HIP_OK) return st;
+  if (rows <= 0 || cols <= 0 || !colptr || !rowind || !val || !v || !out)
+    return fail(AMG_HIP_EINVAL, "bad argument");
+  Sparse M = from_raw(cols, rows, colptr, rowind, val);
+  std::string e = validate(M, "M");
+  if (!e.empty()) return fail(AMG_HIP_EINVAL, e);
+  Sparse Mr = transpose(M);
+  DevCsr D;
+  DevMem dv, dout;
+  HIP_TRY(upload_csr(Mr, &D));
+  HIP_TRY(upload(dv, v, (size_t)cols));
+  HIP_TRY(dout.alloc(sizeof(double) * rows));
+  HIP_TRY(launch_csr(CSR_SPMV, rows, D.nnz, D.max_block_nnz, D.max_row_nnz, D.rowptr(),
+                     D.col(), D.v(), dv.as<double>(), nullptr, dout.as<double>(), 1.0, 0,
+                     nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * rows, hipMemcpyDeviceToHost));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_linear_restrict(int64_t n_h, int64_t n_H, const double* r, double* f_H) {
+  amg_hip_status st = need_device();
+  if (st != AMG_HIP_OK) return st;
+  if (n_h <= 0 || n_H <= 0 || !r || !f_H) return fail(AMG_HIP_EINVAL, "bad argument");
+  DevMem dr, df;
+  HIP_TRY(upload(dr, r, (size_t)n_h));
+  HIP_TRY(df.alloc(sizeof(double) * n_H));
+  HIP_TRY(launch_linear_restrict(n_h, n_H, dr.as<double>(), df.as<double>(), nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(f_H, df.p, sizeof(double) * n_H, hipMemcpyDeviceToHost));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_linear_prolong_add(int64_t n_h, int64_t n_H, const double* u_H,
+                                          double* u_h) {
+  amg_hip_status st = need_device();
+  if (st != AMG_HIP_OK) return st;
+  if (n_h <= 0 || n_H <= 0 || !u_H || !u_h) return fail(AMG_HIP_EINVAL, "bad argument");
+  DevMem dH, dh;
+  HIP_TRY(upload(dH, u_H, (size_t)n_H));
+  HIP_TRY(upload(dh, u_h, (size_t)n_h));
+  HIP_TRY(launch_linear_prolong_add(n_h, n_H, dH.as<double>(), dh.as<double>(), nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(u_h, dh.p, sizeof(double) * n_h, hipMemcpyDeviceToHost));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_rss_host(int64_t n, const int32_t* colptr, const int32_t* rowind,
+                                const double* val, const double* u, const double* b,
+                                double* out) {
+  amg_hip_status st = need_device();
+  if (st != AMG_HIP_OK) return st;
+  if (n <= 0 || !colptr || !rowind || !val || !u || !b || !out)
+    return fail(AMG_HIP_EINVAL, "bad argument");
+  Sparse A = from_raw(n, n, colptr, rowind, val);
+  std::string v = validate(A, "A");
+  if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
+  Sparse Ar = transpose(A);
+  DevCsr D;
+  DevMem du, db, dt, sc;
+  HIP_TRY(upload_csr(Ar, &D));
+  HIP_TRY(upload(du, u, (size_t)n));
+  HIP_TRY(upload(db, b, (size_t)n));
+  HIP_TRY(dt.alloc(sizeof(double) * n));
+  HIP_TRY(sc.alloc(sizeof(double) * 1100));
+  HIP_TRY(launch_csr(CSR_RSSQ, n, D.nnz, D.max_block_nnz, D.max_row_nnz, D.rowptr(), D.col(),
+                     D.v(), du.as<double>(), db.as<double>(), dt.as<double>(), 1.0, 0, nullptr));
+  HIP_TRY(launch_sum(n, dt.as<double>(), sc.as<double>() + 1024, sc.as<double>(), 0, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, sc.as<double>() + 1024, sizeof(double), hipMemcpyDeviceToHost));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_coarse_solve(int64_t n, const int32_t* colptr, const int32_t* rowind,
+                                    const double* val, const double* f, double* x,
+                                    int64_t* halfbw) {
+  amg_hip_status st = need_device();
+  if (st != AMG_HIP_OK) return st;
+  if (n <= 0 || !colptr || !rowind || !val || !f || !x) return fail(AMG_HIP_EINVAL, "bad argument");
+  Sparse A = from_raw(n, n, colptr, rowind, val);
+  std::string v = validate(A, "A");
+  if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
+  BandFactor F;
+  std::string e = band_factor(A, (size_t)8 << 30, &F);
+  if (!e.empty()) return fail(AMG_HIP_EINVAL, e);
+  if (halfbw) *halfbw = F.w;
+  if (F.w > 63) return fail(AMG_HIP_EUNSUPPORTED, "half-bandwidth > 63");
+  DevMem dl, dd, df, dx;
+  HIP_TRY(upload(dl, F.lcol.data(), F.lcol.size()));
+  HIP_TRY(upload(dd, F.d.data(), F.d.size()));
+  HIP_TRY(upload(df, f, (size_t)n));
+  HIP_TRY(dx.alloc(sizeof(double) * n));
+  HIP_TRY(launch_band_solve(n, (int)F.w, dl.as<double>(), dd.as<double>(), df.as<double>(),
+                            dx.as<double>(), nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(x, dx.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return AMG_HIP_OK;
+}
+
+// SmootherBase::smooth for the built-in kinds, on host arrays.
+amg_hip_status amg_hip_smooth(int32_t kind, int64_t n, const int32_t* colptr,
+                              const int32_t* rowind, const double* val, double* u,
+                              const double* b, double omega, double tol, int64_t every,
+                              int64_t n_iters, int64_t* iters, int32_t* converged) {
+  amg_hip_status st = need_device();
+  if (st != AMG_HIP_OK) return st;
+  if (n <= 0 || !colptr || !rowind || !val || !u || !b) return fail(AMG_HIP_EINVAL, "bad argument");
+  if (kind == AMG_HIP_SM_SOR && (omega > 2 || omega < 0))
+    return fail(AMG_HIP_EINVAL, "`omega` must be in [0, 2] but got omega=" + std::to_string(omega) + "\n");
+  if (kind == AMG_HIP_SM_REF_JACOBI && every == 0)
+    return fail(AMG_HIP_EINVAL, "AMG::Jacobi divides by compute_error_every_n_iters (smoother.hpp:258); it must be non-zero");
+  if (kind == AMG_HIP_SM_SOR && every == 0)
+    return fail(AMG_HIP_EINVAL, "AMG::SuccessiveOverRelaxation divides by compute_error_every_n_iters (smoother.hpp:367); it must be non-zero");
+  Sparse A = from_raw(n, n, colptr, rowind, val);
+  std::string v = validate(A, "A");
+  if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
+  Sparse Ar = transpose(A);
+  DevCsr Drows;  // CSR(A) for rss and the row-addressed smoothers
+  DevCsr Dcols;  // CSC arrays as rows
+  const bool sym = same_arrays(A, Ar);
+  HIP_TRY(upload_csr(Ar, &Drows));
+  if (!sym) HIP_TRY(upload_csr(A, &Dcols));
+  const DevCsr& Dc = sym ? Drows : Dcols;
+  DevMem du, db, dt, sc;
+  HIP_TRY(upload(du, u, (size_t)n));
+  HIP_TRY(upload(db, b, (size_t)n));
+  HIP_TRY(dt.alloc(sizeof(double) * n));
+  HIP_TRY(sc.alloc(sizeof(double) * 1100));
+  LexOnDev Lf, Lb;
+  if (kind == AMG_HIP_SM_SPGS) {
+    LexSchedule F, B;
+    std::string e = build_lex_schedule(A, false, 16, &F);
+    if (e.empty()) e = build_lex_schedule(A, true, 16, &B);
+    if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
+    HIP_TRY(upload_lex(F, &Lf));
+    HIP_TRY(upload_lex(B, &Lb));
+  } else if (kind == AMG_HIP_SM_REF_JACOBI || kind == AMG_HIP_SM_SOR) {
+    LexSchedule F;
+    std::string e = build_lex_schedule(Ar, false, 16, &F);
+    if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
+    HIP_TRY(upload_lex(F, &Lf));
+  } else if (kind == AMG_HIP_SM_JACOBI) {
+  } else {
+    return fail(AMG_HIP_EUNSUPPORTED, "smoother kind not available as a stand-alone call");
+  }
+  int64_t iter = 0;
+  double error = 100;  // smoother.hpp:194
+  double* cur = du.as<double>();
+  double* alt = dt.as<double>();
+  const bool check = (kind <= AMG_HIP_SM_SOR);
+  while (iter < n_iters && (!check || error > tol)) {
+    if (kind == AMG_HIP_SM_SPGS) {
+      HIP_TRY(launch_gs_lex(Lf.d, db.as<double>(), cur, 0, 1.0, nullptr));
+      HIP_TRY(launch_gs_lex(Lb.d, db.as<double>(), cur, 0, 1.0, nullptr));
+    } else if (kind == AMG_HIP_SM_REF_JACOBI) {
+      HIP_TRY(launch_gs_lex(Lf.d, db.as<double>(), cur, 1, 1.0, nullptr));
+    } else if (kind == AMG_HIP_SM_SOR) {
+      HIP_TRY(launch_gs_lex(Lf.d, db.as<double>(), cur, 2, omega, nullptr));
+    } else {
+      HIP_TRY(launch_csr(CSR_JACOBI, n, Dc.nnz, Dc.max_block_nnz, Dc.max_row_nnz, Dc.rowptr(),
+                         Dc.col(), Dc.v(), cur, db.as<double>(), alt, omega, 0, nullptr));
+      std::swap(cur, alt);
+    }
+    iter += 1;
+    if (check && every != 0 && iter % every == 0) {
+      HIP_TRY(launch_csr(CSR_RSSQ, n, Drows.nnz, Drows.max_block_nnz, Drows.max_row_nnz,
+                         Drows.rowptr(), Drows.col(), Drows.v(), cur, db.as<double>(), alt, 1.0,
+                         0, nullptr));
+      HIP_TRY(launch_sum(n, alt, sc.as<double>() + 1024, sc.as<double>(), 0, nullptr));
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipMemcpy(&error, sc.as<double>() + 1024, sizeof(double), hipMemcpyDeviceToHost));
+    }
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(u, cur, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (iters) *iters = iter;
+  if (converged) *converged = error <= tol;
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_spgs_sweep(int32_t dir, int64_t n, const int32_t* colptr,
+                                  const int32_t* rowind, const double* val, double* u,
+                                  const double* b) {
+  amg_hip_status st = need_device();
+  if (st != AMG_HIP_OK) return st;
+  if (n <= 0 || !colptr || !rowind || !val || !u || !b) return fail(AMG_HIP_EINVAL, "bad argument");
+  Sparse A = from_raw(n, n, colptr, rowind, val);
+  std::string v = validate(A, "A");
+  if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
+  LexSchedule S;
+  std::string e = build_lex_schedule(A, dir < 0, 16, &S);
+  if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
+  LexOnDev L;
+  HIP_TRY(upload_lex(S, &L));
+  DevMem du, db;
+  HIP_TRY(upload(du, u, (size_t)n));
+  HIP_TRY(upload(db, b, (size_t)n));
+  HIP_TRY(launch_gs_lex(L.d, db.as<double>(), du.as<double>(), 0, 1.0, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(u, du.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return AMG_HIP_OK;
+}
+
+// ---- generators -----------------------------------------------------------------
+int64_t amg_hip_laplacian(int32_t dim, int64_t n, int32_t* colptr, int32_t* rowind,
+                          double* val) {
+  if ((dim != 2 && dim != 3) || n <= 0) {
+    g_err = "laplacian: dim must be 2 or 3 and n positive";
+    return -1;
+  }
+  const double N = std::pow((double)n, dim);
+  if (N * (2 * dim + 1) >= 2147483647.0) {
+    g_err = "laplacian: nnz exceeds int32 indices";
+    return -1;
+  }
+  if (!colptr && !rowind && !val) {  // size query
+    const int64_t nn = (dim == 2) ? n * n : n * n * n;
+    const int64_t faces = (dim == 2) ? 2 * n * (n - 1) : 3 * n * n * (n - 1);
+    return nn + 2 * faces;
+  }
+  Sparse A = laplacian(dim, n);
+  if (colptr) std::memcpy(colptr, A.ptr.data(), sizeof(int32_t) * A.ptr.size());
+  if (rowind) std::memcpy(rowind, A.idx.data(), sizeof(int32_t) * A.idx.size());
+  if (val) std::memcpy(val, A.val.data(), sizeof(double) * A.val.size());
+  return A.nnz();
+}
+amg_hip_status amg_hip_rhs(int32_t dim, int64_t n, double* b) {
+  if ((dim != 2 && dim != 3) || n <= 0 || !b) return fail(AMG_HIP_EINVAL, "bad argument");
+  rhs(dim, n, b);
+  return AMG_HIP_OK;
+}
+
+// ---- device-pointer launchers ------------------------------------------------------
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static amg_hip_status dev_csr(int mode, int64_t nrows, int64_t nnz, int32_t max_block_nnz,
+                              int32_t max_row_nnz, const int32_t* rowptr, const int32_t* col,
+                              const double* val, const double* x, const double* f, double* out,
+                              double omega, int64_t diag_shift, void* stream) {
+  if (nrows < 0 || nnz < 0 || !rowptr || !col || !val || !x || !out)
+    return fail(AMG_HIP_EINVAL, "bad argument");
+  if (!aligned16(col) || !aligned16(val))
+    return fail(AMG_HIP_EINVAL, "col/val device pointers must be 16-byte aligned");
+  if (nrows == 0) return AMG_HIP_OK;
+  HIP_TRY(launch_csr(mode, nrows, nnz, max_block_nnz, max_row_nnz, rowptr, col, val, x, f, out,
+                     omega, diag_shift, (hipStream_t)stream));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_csr_shape(int64_t nrows, const int32_t* rowptr_host,
+                                 int32_t* max_block_nnz, int32_t* max_row_nnz) {
+  if (nrows < 0 || !rowptr_host) return fail(AMG_HIP_EINVAL, "bad argument");
+  int mb = 0, mr = 0;
+  for (int64_t r = 0; r < nrows; ++r) mr = std::max(mr, rowptr_host[r + 1] - rowptr_host[r]);
+  for (int64_t r = 0; r < nrows; r += 256) {
+    const int64_t e = std::min<int64_t>(r + 256, nrows);
+    mb = std::max(mb, rowptr_host[e] - rowptr_host[r]);
+  }
+  if (max_block_nnz) *max_block_nnz = mb;
+  if (max_row_nnz) *max_row_nnz = mr;
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_dev_residual(int64_t nrows, int64_t nnz, int32_t max_block_nnz,
+                                    int32_t max_row_nnz, const int32_t* rowptr,
+                                    const int32_t* col, const double* val, const double* u,
+                                    const double* f, double* r, void* stream) {
+  if (!f) return fail(AMG_HIP_EINVAL, "bad argument");
+  return dev_csr(CSR_RESID, nrows, nnz, max_block_nnz, max_row_nnz, rowptr, col, val, u, f, r,
+                 1.0, 0, stream);
+}
+amg_hip_status amg_hip_dev_jacobi(int64_t nrows, int64_t nnz, int32_t max_block_nnz,
+                                  int32_t max_row_nnz, const int32_t* rowptr,
+                                  const int32_t* col, const double* val, const double* u_in,
+                                  const double* b, double* u_out, double omega,
+                                  int64_t diag_shift, void* stream) {
+  if (!b) return fail(AMG_HIP_EINVAL, "bad argument");
+  return dev_csr(CSR_JACOBI, nrows, nnz, max_block_nnz, max_row_nnz, rowptr, col, val, u_in, b,
+                 u_out, omega, diag_shift, stream);
+}
+amg_hip_status amg_hip_dev_spmv(int64_t nrows, int64_t nnz, int32_t max_block_nnz,
+                                int32_t max_row_nnz, const int32_t* rowptr, const int32_t* col,
+                                const double* val, const double* v, double* out, void* stream) {
+  return dev_csr(CSR_SPMV, nrows, nnz, max_block_nnz, max_row_nnz, rowptr, col, val, v, nullptr,
+                 out, 1.0, 0, stream);
+}
+amg_hip_status amg_hip_dev_axpy1(int64_t n, const double* x, double* y, void* stream) {
+  if (n < 0 || !x || !y) return fail(AMG_HIP_EINVAL, "bad argument");
+  HIP_TRY(launch_add_inplace(n, x, y, (hipStream_t)stream));
+  return AMG_HIP_OK;
+}
+amg_hip_status amg_hip_dev_sumsq(int64_t n, const double* r, double* out, double* scratch,
+                                 void* stream) {
+  if (n < 0 || !r || !out || !scratch) return fail(AMG_HIP_EINVAL, "bad argument");
+  HIP_TRY(launch_sum(n, r, out, scratch, 1, (hipStream_t)stream));
+  return AMG_HIP_OK;
+}
+
+}  // extern "C"

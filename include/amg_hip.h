@@ -1,0 +1,250 @@
+/* =============================================================================
+ * amg_hip.h -- C ABI of the MI355X-native V-cycle (libamg_hip.so)
+ *
+ * Drop-in boundary for the V-cycle hot path of jfdev001/algebraic-multigrid.
+ * The reference is header-only C++ (no FFI of its own); these entry points are
+ * what a binding of its public interface binds.  Each one cites the reference
+ * interface it replaces (paths relative to the reference repository).
+ * include/amg/ *.hpp is the C++ drop-in layer (AMG::Multigrid<> etc.) written on
+ * top of exactly these functions; INTEGRATION.md shows both.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no C++/torch types; all indices int32 (Eigen's
+ *    default StorageIndex), all values fp64 (the only EleType the reference
+ *    instantiates, test/testlib.cpp throughout).
+ *  - sparse matrices are COMPRESSED COLUMN (Eigen::SparseMatrix<double> default):
+ *    colptr[cols+1], rowind[nnz] ascending inside a column, val[nnz].
+ *  - every function returns an amg_hip_status; amg_hip_last_error() gives the
+ *    thread-local message of the last failure.  The C++ layer re-throws
+ *    AMG_HIP_EINVAL as std::invalid_argument with the reference's message text
+ *    (multigrid.hpp:165-178, smoother.hpp:286-293).
+ *  - there is NO CPU fallback: without a usable HIP device every compute entry
+ *    point fails with AMG_HIP_EHIP.
+ *  - one handle = one host thread at a time (the reference is not thread-safe
+ *    either); different handles are independent.
+ * ===========================================================================*/
+#ifndef AMG_HIP_H
+#define AMG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  AMG_HIP_OK = 0,
+  AMG_HIP_EINVAL = 1,       /* bad argument (-> std::invalid_argument)        */
+  AMG_HIP_EHIP = 2,         /* HIP runtime / device failure                    */
+  AMG_HIP_ENOMEM = 3,       /* host or device allocation failed                */
+  AMG_HIP_EUNSUPPORTED = 4  /* valid request this build cannot run on device   */
+} amg_hip_status;
+
+/* Smoother plug-ins (smoother.hpp).  0-2 are the reference's three classes;
+ * 3-4 are build-side additions the reference does not contain.   */
+typedef enum {
+  AMG_HIP_SM_SPGS = 0,          /* AMG::SparseGaussSeidel smoother.hpp:86-216:
+                                   n_iters x (forward + backward lexicographic
+                                   sweep), column-as-row walk, exact order      */
+  AMG_HIP_SM_REF_JACOBI = 1,    /* AMG::Jacobi smoother.hpp:223-264 (an in-place
+                                   forward Gauss-Seidel, row addressed)         */
+  AMG_HIP_SM_SOR = 2,           /* AMG::SuccessiveOverRelaxation :271-373       */
+  AMG_HIP_SM_JACOBI = 3,        /* true two-buffer weighted Jacobi              */
+  AMG_HIP_SM_MULTICOLOR_GS = 4  /* symmetric multicolour Gauss-Seidel           */
+} amg_hip_smoother;
+
+/* Options of amg_hip_create.  Zero-initialise, then amg_hip_default_options. */
+typedef struct {
+  int32_t smoother;        /* amg_hip_smoother; default AMG_HIP_SM_SPGS         */
+  int32_t smoother_iters;  /* SmootherBase::n_iters (smoother.hpp:37); default 1
+                              (= SparseGaussSeidel(), smoother.hpp:183-187)     */
+  double omega;            /* SOR / weighted-Jacobi relaxation; default 1.0     */
+  int32_t device;          /* HIP device ordinal; -1 = current device           */
+  int32_t use_graph;       /* 1: replay the V-cycle as one hipGraph (default)   */
+  int32_t stencil_transfers; /* 1 (default): when P/R are the built-in
+                              LinearInterpolator, use the matrix-free stride-2
+                              kernels (bit-identical to the CSR path)           */
+  int32_t reserved[8];
+} amg_hip_options;
+
+typedef struct amg_hip_solver amg_hip_solver; /* opaque; owns device memory    */
+
+const char* amg_hip_last_error(void);
+void amg_hip_default_options(amg_hip_options* o);
+
+/* Number of usable HIP devices (0 when none; never fails). */
+int amg_hip_device_count(void);
+
+/* ---- AMG::Multigrid<double> (multigrid.hpp:151-244, ctor = SETUP) ----------
+ * A (n x n CSC) and b are copied (multigrid.hpp:193,201).  Level sizes follow
+ * n_H = (n_h+1)/2 - 1 (multigrid.hpp:127-130); transfer operators are the
+ * built-in LinearInterpolator (interpolator.hpp:106-141) unless custom P/R are
+ * given; coarse operators are Galerkin R*(A*P) in Eigen's summation order with
+ * structural zeros kept (multigrid.hpp:219-223); the coarsest level is factored
+ * (banded LDL^T, replaces Eigen::SimplicialLDLT multigrid.hpp:240-243).
+ * Everything is uploaded; u_0 = 0.                                            */
+amg_hip_status amg_hip_create(int64_t n, const int32_t* colptr,
+                              const int32_t* rowind, const double* val,
+                              const double* b, int32_t n_levels,
+                              const amg_hip_options* opts,
+                              amg_hip_solver** out);
+
+/* Same, for a user InterpolatorBase subclass (interpolator.hpp:43-44): the C++
+ * layer runs make_operators(n_h, n_H, level) on the host for every level and
+ * hands over P_l (n_l x n_{l+1}) and R_l (n_{l+1} x n_l), l = 0..n_levels-2,
+ * as arrays of CSC triples.                                                    */
+amg_hip_status amg_hip_create_custom(int64_t n, const int32_t* colptr,
+                                     const int32_t* rowind, const double* val,
+                                     const double* b, int32_t n_levels,
+                                     const int32_t* const* P_colptr,
+                                     const int32_t* const* P_rowind,
+                                     const double* const* P_val,
+                                     const int32_t* const* R_colptr,
+                                     const int32_t* const* R_rowind,
+                                     const double* const* R_val,
+                                     const amg_hip_options* opts,
+                                     amg_hip_solver** out);
+
+void amg_hip_destroy(amg_hip_solver* s); /* ~Multigrid, multigrid.hpp:135 */
+
+/* One V-cycle, multigrid.hpp:263-305 (including the smoothing + residual on
+ * the coarsest level).  Asynchronous on the solver's stream.      */
+amg_hip_status amg_hip_vcycle(amg_hip_solver* s);
+/* n back-to-back V-cycles (what bench.py times); returns after enqueueing.   */
+amg_hip_status amg_hip_vcycles(amg_hip_solver* s, int32_t n);
+/* Block until the solver's stream is idle. */
+amg_hip_status amg_hip_sync(amg_hip_solver* s);
+
+/* Multigrid::solve(), multigrid.hpp:311-337: while (iter < n_iters && error >
+ * tol) { vcycle(); if (++iter % every == 0) error = rss }.  error starts at 100.
+ * *converged = (error <= tol).  Prints nothing (the C++ layer prints the
+ * reference's "AMG converged after N iterations." line).                      */
+amg_hip_status amg_hip_solve(amg_hip_solver* s, double tol, int64_t every,
+                             int64_t n_iters, int64_t* iters, double* last_rss,
+                             int32_t* converged);
+
+/* AMG::rss(A_0, u_0, b), common.hpp:17-27 (device tree reduction; agrees with
+ * the sequential sum to ~1e-15 relative). */
+amg_hip_status amg_hip_rss(amg_hip_solver* s, double* out);
+
+/* Getters, multigrid.hpp:339-354. */
+int32_t amg_hip_n_levels(const amg_hip_solver* s);
+int64_t amg_hip_get_n_dofs(const amg_hip_solver* s, int32_t level);
+int64_t amg_hip_get_level_nnz(const amg_hip_solver* s, int32_t level);
+/* get_coefficient_matrix(level): CSC copy out (arrays sized by the caller). */
+amg_hip_status amg_hip_get_level_matrix(const amg_hip_solver* s, int32_t level,
+                                        int32_t* colptr, int32_t* rowind,
+                                        double* val);
+/* which: 0 = P_level (n_l x n_{l+1}), 1 = R_level.  Returns nnz (<0: error). */
+int64_t amg_hip_get_transfer_nnz(const amg_hip_solver* s, int32_t level, int32_t which);
+amg_hip_status amg_hip_get_transfer(const amg_hip_solver* s, int32_t level,
+                                    int32_t which, int32_t* colptr,
+                                    int32_t* rowind, double* val);
+/* which: 0 = get_soln, 1 = get_rhs, 2 = residual vector (multigrid.hpp:107).
+ * Synchronises the stream, then copies n_dofs(level) doubles to/from host.    */
+amg_hip_status amg_hip_get_vec(amg_hip_solver* s, int32_t level, int32_t which,
+                               double* out);
+amg_hip_status amg_hip_set_vec(amg_hip_solver* s, int32_t level, int32_t which,
+                               const double* in);
+/* Half-bandwidth of the factored coarsest operator. */
+int64_t amg_hip_coarse_halfbw(const amg_hip_solver* s);
+/* Multicolour smoother: colour of every dof of `level` (n_dofs int32) and the
+ * colour count, so a CPU twin can replay the same colouring.                   */
+amg_hip_status amg_hip_get_colors(const amg_hip_solver* s, int32_t level,
+                                  int32_t* color, int32_t* n_colors);
+
+/* Sum over levels of the algorithmic HBM bytes of one V-cycle (SURVEY 8(d)
+ * formulae) and the per-sweep bytes of level 0; used by bench.py.             */
+amg_hip_status amg_hip_cycle_bytes(const amg_hip_solver* s, double* cycle_bytes,
+                                   double* fine_sweep_bytes);
+
+/* ---- stand-alone plug-in operations on host arrays (run on the device) -----
+ * SmootherBase::smooth(A, u, b), smoother.hpp:63-65, for the built-in kinds.
+ * u is updated in place.  every = compute_error_every_n_iters (0 = never, the
+ * SparseGaussSeidel() default); *iters and *converged mirror the reference's
+ * loop (smoother.hpp:195-203).  For kinds 3-4 `n_iters` counts sweeps /
+ * symmetric colour passes and tol/every are ignored.                          */
+amg_hip_status amg_hip_smooth(int32_t kind, int64_t n, const int32_t* colptr,
+                              const int32_t* rowind, const double* val,
+                              double* u, const double* b, double omega,
+                              double tol, int64_t every, int64_t n_iters,
+                              int64_t* iters, int32_t* converged);
+/* One lexicographic sweep, dir=+1 forward (smoother.hpp:148-157) or -1 backward
+ * (:167-174). */
+amg_hip_status amg_hip_spgs_sweep(int32_t dir, int64_t n, const int32_t* colptr,
+                                  const int32_t* rowind, const double* val,
+                                  double* u, const double* b);
+/* r = f - A*u, multigrid.hpp:272-274 (Eigen order: ascending column per row). */
+amg_hip_status amg_hip_residual(int64_t n, const int32_t* colptr,
+                                const int32_t* rowind, const double* val,
+                                const double* u, const double* f, double* r);
+/* out = M*v for a rows x cols CSC matrix: InterpolatorBase::prolongation /
+ * restriction, interpolator.hpp:52-56,64-68. */
+amg_hip_status amg_hip_spmv(int64_t rows, int64_t cols, const int32_t* colptr,
+                            const int32_t* rowind, const double* val,
+                            const double* v, double* out);
+/* Built-in LinearInterpolator transfers without a matrix (bit-identical to
+ * amg_hip_spmv on make_operators' P/R): f_H = R r  and  u_h += P u_H
+ * (interpolator.hpp:106-141, multigrid.hpp:281-282,294-296). */
+amg_hip_status amg_hip_linear_restrict(int64_t n_h, int64_t n_H, const double* r,
+                                       double* f_H);
+amg_hip_status amg_hip_linear_prolong_add(int64_t n_h, int64_t n_H,
+                                          const double* u_H, double* u_h);
+/* AMG::rss(A, u, b), common.hpp:17-27. */
+amg_hip_status amg_hip_rss_host(int64_t n, const int32_t* colptr,
+                                const int32_t* rowind, const double* val,
+                                const double* u, const double* b, double* out);
+/* x = A^-1 f by the banded LDL^T used for the coarsest level
+ * (multigrid.hpp:287-288); *halfbw returns the bandwidth found. */
+amg_hip_status amg_hip_coarse_solve(int64_t n, const int32_t* colptr,
+                                    const int32_t* rowind, const double* val,
+                                    const double* f, double* x, int64_t* halfbw);
+
+/* ---- Grid<double> problem generators (grid.hpp), host side -----------------
+ * laplacian: grid.hpp:88-98 (dim 2) / 7-point analogue (dim 3).  Call with NULL
+ * arrays to get nnz.  rhs: grid.hpp:108-140, default Gaussian forcing.        */
+int64_t amg_hip_laplacian(int32_t dim, int64_t n, int32_t* colptr,
+                          int32_t* rowind, double* val);
+amg_hip_status amg_hip_rhs(int32_t dim, int64_t n, double* b);
+
+/* ---- device-pointer kernel launchers ----------------------------------------
+ * For hosts that own device memory and streams themselves (the multi-GPU
+ * row-block driver: torch tensors + torch.distributed halo exchange).  All
+ * pointers are DEVICE pointers; `stream` is a hipStream_t (NULL = default).
+ * CSR here = row-major view (rowptr/col/val); for a symmetric A the CSC arrays
+ * are the CSR arrays.  Column indices address `u` directly, so a rank passes a
+ * halo-extended local vector and locally renumbered columns.                  */
+/* Launch parameters of the CSR kernels, computed from a HOST copy of rowptr:
+ * max entries in any block of 256 consecutive rows, and the longest row.     */
+amg_hip_status amg_hip_csr_shape(int64_t nrows, const int32_t* rowptr_host,
+                                 int32_t* max_block_nnz, int32_t* max_row_nnz);
+amg_hip_status amg_hip_dev_residual(int64_t nrows, int64_t nnz, int32_t max_block_nnz,
+                                    int32_t max_row_nnz, const int32_t* rowptr,
+                                    const int32_t* col, const double* val,
+                                    const double* u, const double* f, double* r,
+                                    void* stream);
+/* u_out[i] = u_in[i'] + omega*((b[i]-sum_{j!=i'} a_ij u_in[j])/a_ii' - u_in[i'])
+ * with i' = i + diag_shift: the column that is row i's diagonal (a rank passes
+ * the offset of its first owned row inside its halo-extended vector). b and
+ * u_out are indexed by the local row i.                                       */
+amg_hip_status amg_hip_dev_jacobi(int64_t nrows, int64_t nnz, int32_t max_block_nnz,
+                                  int32_t max_row_nnz, const int32_t* rowptr,
+                                  const int32_t* col, const double* val,
+                                  const double* u_in, const double* b,
+                                  double* u_out, double omega, int64_t diag_shift,
+                                  void* stream);
+amg_hip_status amg_hip_dev_spmv(int64_t nrows, int64_t nnz, int32_t max_block_nnz,
+                                int32_t max_row_nnz, const int32_t* rowptr,
+                                const int32_t* col, const double* val,
+                                const double* v, double* out, void* stream);
+/* y[i] += x[i] */
+amg_hip_status amg_hip_dev_axpy1(int64_t n, const double* x, double* y, void* stream);
+/* *out (device double) = sum_i r[i]^2 ; scratch >= 8 KiB device memory */
+amg_hip_status amg_hip_dev_sumsq(int64_t n, const double* r, double* out,
+                                 double* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMG_HIP_H */

@@ -17,3 +17,14 @@ def oracle():
     from oracle import oracle as O
     O.build()
     return O
+
+
+@pytest.fixture(scope="session")
+def amg():
+    """ctypes binding of libamg_hip.so (the product's C ABI)."""
+    pkg = os.path.join(ROOT, "algebraic-multigrid_amd")
+    if pkg not in sys.path:
+        sys.path.insert(0, pkg)
+    import amg_ctypes
+    amg_ctypes.lib()
+    return amg_ctypes
