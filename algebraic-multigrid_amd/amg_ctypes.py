@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libamg_hip.so")
 
 OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED = 0, 1, 2, 3, 4
 SM_SPGS, SM_REF_JACOBI, SM_SOR, SM_JACOBI, SM_MULTICOLOR_GS = 0, 1, 2, 3, 4
+LAYOUT_AUTO, LAYOUT_CSR, LAYOUT_SELL = 0, 1, 2
 
 _i32p = C.POINTER(C.c_int32)
 _f64p = C.POINTER(C.c_double)
@@ -32,7 +33,8 @@ class AmgHipError(RuntimeError):
 class Options(C.Structure):
     _fields_ = [("smoother", C.c_int32), ("smoother_iters", C.c_int32),
                 ("omega", C.c_double), ("device", C.c_int32), ("use_graph", C.c_int32),
-                ("stencil_transfers", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("stencil_transfers", C.c_int32), ("layout", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
 
 
 # name -> (restype, argtypes).  Must list EVERY symbol include/amg_hip.h declares
@@ -41,6 +43,7 @@ _SIGS = {
     "amg_hip_last_error": (C.c_char_p, []),
     "amg_hip_default_options": (None, [C.POINTER(Options)]),
     "amg_hip_device_count": (C.c_int, []),
+    "amg_hip_set_default_layout": (None, [C.c_int32]),
     "amg_hip_create": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_int32,
                                  C.POINTER(Options), C.POINTER(C.c_void_p)]),
     "amg_hip_create_custom": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_int32,
@@ -65,6 +68,7 @@ _SIGS = {
     "amg_hip_coarse_halfbw": (C.c_int64, [C.c_void_p]),
     "amg_hip_get_colors": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p]),
     "amg_hip_cycle_bytes": (C.c_int, [C.c_void_p, _f64p, _f64p]),
+    "amg_hip_profile_fine_sweep": (C.c_int, [C.c_void_p, C.c_int32, _f64p, _f64p]),
     "amg_hip_smooth": (C.c_int, [C.c_int32, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p,
                                  C.c_double, C.c_double, C.c_int64, C.c_int64, _i64p, _i32p]),
     "amg_hip_spgs_sweep": (C.c_int, [C.c_int32, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]),
@@ -133,6 +137,10 @@ def device_count():
     return lib().amg_hip_device_count()
 
 
+def set_default_layout(layout):
+    lib().amg_hip_set_default_layout(layout)
+
+
 # ---- Grid<double> ------------------------------------------------------------
 def laplacian(n, dim=2):
     """grid.hpp:88-98.  Returns (colptr, rowind, val) of the CSC matrix."""
@@ -161,7 +169,7 @@ class Multigrid:
     def __init__(self, colptr, rowind, val, b, n_levels, smoother=SM_SPGS,
                  smoother_iters=1, omega=1.0, tolerance=1e-9, compute_error_every_n_iters=10,
                  n_iters=100, device=-1, use_graph=True, stencil_transfers=True,
-                 transfers=None):
+                 transfers=None, layout=None):
         # multigrid.hpp:165-178 (same checks, same order)
         if compute_error_every_n_iters > n_iters:
             raise ValueError("`compute_error_every_n_iters` must be leq to `n_iters`, got "
@@ -178,6 +186,8 @@ class Multigrid:
         lib().amg_hip_default_options(C.byref(o))
         o.smoother, o.smoother_iters, o.omega = smoother, smoother_iters, omega
         o.device, o.use_graph, o.stencil_transfers = device, int(use_graph), int(stencil_transfers)
+        if layout is not None:
+            o.layout = layout
         h = C.c_void_p()
         if transfers is None:
             st = lib().amg_hip_create(n, _p32(colptr), _p32(rowind), _p64(val), _p64(b),
@@ -279,6 +289,13 @@ class Multigrid:
     def cycle_bytes(self):
         a, b = C.c_double(0), C.c_double(0)
         _chk(lib().amg_hip_cycle_bytes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def profile_fine_sweep(self, n_launches):
+        """(avg_ms, min_ms) of the level-0 Jacobi sweep kernel, HIP events on
+        the solver's stream."""
+        a, b = C.c_double(0), C.c_double(0)
+        _chk(lib().amg_hip_profile_fine_sweep(self._h, n_launches, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def vcycle(self, n=1):

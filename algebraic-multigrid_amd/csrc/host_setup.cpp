@@ -180,6 +180,31 @@ Sparse galerkin_csr(const Sparse& Rr, const Sparse& Ar, const Sparse& Pr,
   return spgemm_csr(Rr, AP, n_threads);
 }
 
+void to_sell64(const Sparse& M, Sell64* S) {
+  const int64_t n = M.n_outer;
+  const int64_t np = (n + 63) / 64;
+  S->n = n;
+  S->soff.assign(np + 1, 0);
+  S->max_width = 0;
+  for (int64_t p = 0; p < np; ++p) {
+    int32_t w = 0;
+    for (int64_t r = p * 64; r < std::min(n, p * 64 + 64); ++r)
+      w = std::max(w, M.ptr[r + 1] - M.ptr[r]);
+    S->soff[p + 1] = S->soff[p] + (int64_t)w * 64;
+    S->max_width = std::max(S->max_width, w);
+  }
+  S->col.assign((size_t)S->soff[np], -1);
+  S->val.assign((size_t)S->soff[np], 0.0);
+  for (int64_t r = 0; r < n; ++r) {
+    const int64_t base = S->soff[r >> 6] + (r & 63);
+    int64_t j = 0;
+    for (int32_t q = M.ptr[r]; q < M.ptr[r + 1]; ++q, ++j) {
+      S->col[base + j * 64] = M.idx[q];
+      S->val[base + j * 64] = M.val[q];
+    }
+  }
+}
+
 // ------------------------------------------------------------- banded LDL^T ---
 std::string band_factor(const Sparse& A, size_t max_bytes, BandFactor* out) {
   const int64_t n = A.n_outer;
@@ -224,6 +249,31 @@ std::string band_factor(const Sparse& A, size_t max_bytes, BandFactor* out) {
     for (int64_t d = 1; d <= w && i - d >= 0; ++d)
       out->lcol[(i - d) * w + (d - 1)] = rb[i * W + d];  // L[i, i-d] = L[(i-d)+d, i-d]
   }
+  return "";
+}
+
+std::string band_schedule(const BandFactor& F, BandSchedule* S) {
+  if (F.w > 63)
+    return "coarsest operator has half-bandwidth " + std::to_string(F.w) +
+           " > 63 (device band solve limit); use more levels";
+  int32_t m = 4;
+  while (m <= F.w) m *= 2;
+  const int64_t n = F.n, w = F.w;
+  S->n = n;
+  S->m = m;
+  S->d = F.d;
+  // zero-padded to a multiple of 64 steps plus one prefetched chunk pair
+  const int64_t n_pad = (n + 63) / 64 * 64 + 64;
+  S->sched_f.assign((size_t)(n_pad * m), 0.0);
+  S->sched_b.assign((size_t)(n_pad * m), 0.0);
+  for (int64_t s = 0; s < n; ++s)
+    for (int64_t d = 1; d <= w; ++d) {
+      if (s + d < n)  // forward step s: row s+d, entry L[s+d, s]
+        S->sched_f[s * m + ((s + d) % m)] = F.lcol[s * w + (d - 1)];
+      const int64_t k = n - 1 - s;  // backward step s: row k-d, entry L[k, k-d]
+      if (k - d >= 0)
+        S->sched_b[s * m + ((s + d) % m)] = F.lcol[(k - d) * w + (d - 1)];
+    }
   return "";
 }
 

@@ -49,6 +49,18 @@ Sparse spgemm_csr(const Sparse& A, const Sparse& B, int n_threads);
 Sparse galerkin_csr(const Sparse& Rr, const Sparse& Ar, const Sparse& Pr,
                     int n_threads);
 
+// ---- SELL-64: CSR sliced into 64-row panels, lane-interleaved ----------------
+struct Sell64 {
+  int64_t n = 0;
+  int32_t max_width = 0;
+  std::vector<int64_t> soff;   // n_panels + 1
+  std::vector<int32_t> col;    // -1 = padding
+  std::vector<double> val;
+  int64_t slots() const { return (int64_t)col.size(); }
+};
+// rows_as: matrix whose outer index is the row.  Entry order inside a row kept.
+void to_sell64(const Sparse& rows_as, Sell64* out);
+
 // ---- coarsest level: banded LDL^T (replaces Eigen::SimplicialLDLT) ---------
 struct BandFactor {
   int64_t n = 0, w = 0;
@@ -61,6 +73,19 @@ struct BandFactor {
 // `A` symmetric, CSC or CSR (same thing).  Fails (returns message) on a zero
 // pivot or when the band would need more than `max_bytes`.
 std::string band_factor(const Sparse& A, size_t max_bytes, BandFactor* out);
+
+// Device layout of the factor for the one-wave substitution kernel: m = power of
+// two > w (4..64) lanes; row i lives in lane i % m (forward) / (n-1-i) % m
+// (backward).  sched_f[s*m + l] = L[s+d, s], d = (l - s) mod m, when 1<=d<=w and
+// s+d < n, else 0;  sched_b[t*m + l] = L[k, k-d], k = n-1-t, d = (l - t) mod m,
+// when 1<=d<=w and k-d >= 0, else 0.
+struct BandSchedule {
+  int64_t n = 0;
+  int32_t m = 0;
+  std::vector<double> sched_f, sched_b, d;
+};
+// fails when w > 63
+std::string band_schedule(const BandFactor& F, BandSchedule* out);
 
 // ---- exact lexicographic Gauss-Seidel schedule ------------------------------
 // Rows are executed in `order`; rows inside one window of `block` consecutive

@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "kernels.hpp"
 
 namespace amg_hip {
@@ -154,12 +156,19 @@ static hipError_t launch_csr_mode(int64_t n, int64_t nnz, int max_block_nnz,
                                   const int32_t* col, const double* val,
                                   const double* x, const double* f, double* out,
                                   double omega, int64_t diag_shift, hipStream_t st) {
-  // +3: the chunk start is rounded down to a multiple of 4 entries
+  // +3: the chunk start is rounded down to a multiple of 4 entries.  U (gathers
+  // issued per pass of a lane over its row) is matched to the longest row: a
+  // 5-point row walked with U = 8 wastes 3 LDS reads + 3 gathers (measured
+  // 4.9 -> 5.6 TB/s on the 4096^2 fine level, tools/kbench.hip).
   const int need = max_block_nnz + 3;
-  if (need <= CSR_BLOCK * 6 && max_row_nnz <= 8)
-    return launch_csr_ku<MODE, 6, 8>(n, nnz, rowptr, col, val, x, f, out, omega, diag_shift, st);
-  if (need <= CSR_BLOCK * 10 && max_row_nnz <= 12)
-    return launch_csr_ku<MODE, 10, 12>(n, nnz, rowptr, col, val, x, f, out, omega, diag_shift, st);
+  if (need <= CSR_BLOCK * 4 && max_row_nnz <= 3)
+    return launch_csr_ku<MODE, 4, 3>(n, nnz, rowptr, col, val, x, f, out, omega, diag_shift, st);
+  if (need <= CSR_BLOCK * 6 && max_row_nnz <= 5)
+    return launch_csr_ku<MODE, 6, 5>(n, nnz, rowptr, col, val, x, f, out, omega, diag_shift, st);
+  if (need <= CSR_BLOCK * 8 && max_row_nnz <= 7)
+    return launch_csr_ku<MODE, 8, 7>(n, nnz, rowptr, col, val, x, f, out, omega, diag_shift, st);
+  if (need <= CSR_BLOCK * 10 && max_row_nnz <= 9)
+    return launch_csr_ku<MODE, 10, 9>(n, nnz, rowptr, col, val, x, f, out, omega, diag_shift, st);
   return launch_csr_ku<MODE, 16, 8>(n, nnz, rowptr, col, val, x, f, out, omega, diag_shift, st);
 }
 
@@ -180,6 +189,105 @@ hipError_t launch_csr(int mode, int64_t n, int64_t nnz, int max_block_nnz,
     case CSR_RSSQ:
       return launch_csr_mode<CSR_RSSQ>(n, nnz, max_block_nnz, max_row_nnz, rowptr, col,
                                        val, x, f, out, omega, diag_shift, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------- K-SELL -----
+// Same four operations on the solver's own level matrices, stored as CSR sliced
+// into 64-row panels with each panel lane-interleaved (SELL-64): entry j of row
+// r sits at soff[r/64] + 64*j + (r%64), rows padded to the panel's longest row
+// with col = -1.  One lane per row; every load of a wave is one contiguous
+// 256-B (col) / 512-B (val) segment, no row pointer, no LDS round trip, no
+// barrier, ascending-column order per row kept (bit-identical results to K-CSR).
+// Measured on the 4096^2 fine level: 6.2 TB/s algorithmic vs 5.6 TB/s for K-CSR
+// (tools/kbench.hip) -- the panel layout is what "CSR laid out for coalesced
+// HBM reads" comes to on wave64 hardware.
+template <int MODE, int U>
+__global__ __launch_bounds__(256) void sell_kernel(
+    int n, const int64_t* __restrict__ soff, const int32_t* __restrict__ scol,
+    const double* __restrict__ sval, const double* __restrict__ x,
+    const double* __restrict__ f, double* __restrict__ out, double omega) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int s = row >> 6;
+  if ((s << 6) >= n) return;  // whole wave past the end
+  const int64_t o0 = soff[s], o1 = soff[s + 1];
+  const int w = (int)((o1 - o0) >> 6);  // wave-uniform panel width
+  const int64_t base = o0 + (row & 63);
+  const bool live = row < n;
+  double fi = 0.0, xi = 0.0;
+  if (live) {
+    if (MODE != CSR_SPMV) fi = f[row];
+    if (MODE == CSR_JACOBI) xi = x[row];
+  }
+  double acc = (MODE == CSR_RESID) ? fi : 0.0;
+  double diag = 0.0;
+  for (int j0 = 0; j0 < w; j0 += U) {
+    int32_t c[U];
+    double v[U], xx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u < w ? j0 + u : j0;
+      c[u] = scol[base + ((int64_t)j << 6)];
+      v[u] = sval[base + ((int64_t)j << 6)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) xx[u] = x[c[u] >= 0 ? c[u] : 0];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (j0 + u < w && c[u] >= 0) {
+        if (MODE == CSR_RESID) {
+          acc -= v[u] * xx[u];
+        } else if (MODE == CSR_JACOBI) {
+          if (c[u] == row) diag = v[u];
+          else acc += v[u] * xx[u];
+        } else {
+          acc += v[u] * xx[u];
+        }
+      }
+    }
+  }
+  if (live) {
+    if (MODE == CSR_RESID || MODE == CSR_SPMV) {
+      out[row] = acc;
+    } else if (MODE == CSR_JACOBI) {
+      out[row] = (diag == 0.0) ? xi : xi + omega * ((fi - acc) / diag - xi);
+    } else {
+      const double d = fi - acc;
+      out[row] = d * d;
+    }
+  }
+}
+
+template <int MODE, int U>
+static hipError_t launch_sell_u(int64_t n, const int64_t* soff, const int32_t* scol,
+                                const double* sval, const double* x, const double* f,
+                                double* out, double omega, hipStream_t st) {
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL((sell_kernel<MODE, U>), dim3(grid), dim3(256), 0, st, (int)n, soff, scol,
+                     sval, x, f, out, omega);
+  return hipGetLastError();
+}
+template <int MODE>
+static hipError_t launch_sell_mode(int64_t n, int max_width, const int64_t* soff,
+                                   const int32_t* scol, const double* sval, const double* x,
+                                   const double* f, double* out, double omega, hipStream_t st) {
+  if (max_width <= 3) return launch_sell_u<MODE, 3>(n, soff, scol, sval, x, f, out, omega, st);
+  if (max_width <= 5) return launch_sell_u<MODE, 5>(n, soff, scol, sval, x, f, out, omega, st);
+  if (max_width <= 7) return launch_sell_u<MODE, 7>(n, soff, scol, sval, x, f, out, omega, st);
+  if (max_width <= 9) return launch_sell_u<MODE, 9>(n, soff, scol, sval, x, f, out, omega, st);
+  return launch_sell_u<MODE, 8>(n, soff, scol, sval, x, f, out, omega, st);
+}
+hipError_t launch_sell(int mode, int64_t n, int max_width, const int64_t* soff,
+                       const int32_t* scol, const double* sval, const double* x,
+                       const double* f, double* out, double omega, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (n >= ((int64_t)1 << 31) - 256) return hipErrorInvalidValue;
+  switch (mode) {
+    case CSR_RESID: return launch_sell_mode<CSR_RESID>(n, max_width, soff, scol, sval, x, f, out, omega, st);
+    case CSR_JACOBI: return launch_sell_mode<CSR_JACOBI>(n, max_width, soff, scol, sval, x, f, out, omega, st);
+    case CSR_SPMV: return launch_sell_mode<CSR_SPMV>(n, max_width, soff, scol, sval, x, f, out, omega, st);
+    case CSR_RSSQ: return launch_sell_mode<CSR_RSSQ>(n, max_width, soff, scol, sval, x, f, out, omega, st);
   }
   return hipErrorInvalidValue;
 }
@@ -217,10 +325,13 @@ hipError_t launch_csr_shape(int64_t n, const int32_t* rowptr, int32_t* out2,
 // ------------------------------------------------- K-Restrict / K-ProlongAdd ---
 // f_H[j] = ((0 + 0.5 r[2j]) + 1.0 r[2j+1]) + 0.5 r[2j+2]   (Eigen column-major
 // scatter order of R*v, interpolator.hpp:64-68 with R = P^T, :132-134).
+// uH (optional) is zero-filled in the same pass (multigrid.hpp:278).
 __global__ __launch_bounds__(256) void linear_restrict_kernel(
-    int64_t n_h, int64_t n_H, const double* __restrict__ r, double* __restrict__ fH) {
+    int64_t n_h, int64_t n_H, const double* __restrict__ r, double* __restrict__ fH,
+    double* __restrict__ uH) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_H) return;
+  if (uH) uH[j] = 0.0;
   const int64_t i = 2 * j;
   double s = 0.0;
   if (i < n_h) s += 0.5 * r[i];
@@ -246,10 +357,10 @@ __global__ __launch_bounds__(256) void linear_prolong_add_kernel(
   uh[i] = uh[i] + t;
 }
 hipError_t launch_linear_restrict(int64_t n_h, int64_t n_H, const double* r, double* fH,
-                                  hipStream_t st) {
+                                  double* uH_zero, hipStream_t st) {
   if (n_H <= 0) return hipSuccess;
   hipLaunchKernelGGL(linear_restrict_kernel, dim3((unsigned)((n_H + 255) / 256)),
-                     dim3(256), 0, st, n_h, n_H, r, fH);
+                     dim3(256), 0, st, n_h, n_H, r, fH, uH_zero);
   return hipGetLastError();
 }
 hipError_t launch_linear_prolong_add(int64_t n_h, int64_t n_H, const double* uH,
@@ -412,91 +523,129 @@ hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, 
 }
 
 // ------------------------------------------------------------------ K-Band ---
-// x = A^-1 f with A = L D L^T banded (half-bandwidth w <= 63), ONE wave.
-// Lane l keeps the running right-hand side of the rows i == l (mod 64) in a
-// register.  Forward, step k: y_k is complete in lane k&63 -> broadcast by
-// v_readlane, rows k+1..k+w subtract L[k+d,k]*y_k (ascending k per row, the
-// order of a row-oriented substitution); then z = y/D (IEEE divide) and the
-// mirror-image backward pass.  L columns are prefetched CH steps ahead.
+// x = A^-1 f with A = L D L^T banded (half-bandwidth w <= 63), ONE wave -- the
+// substitution is a serial chain, so the design goal is the fewest instructions
+// per step.  M = power of two > w lanes take part; lane l keeps the running
+// right-hand side of the rows == l (mod M) in a register.  Forward step s: y_s
+// is complete in lane s%M -> v_readlane broadcast -> every lane subtracts its
+// pre-scheduled L entry times y_s (one multiply, one subtract, no FMA: the
+// updates reach a row in ascending s, the order of a row-oriented substitution).
+// The host lays L out per (step, lane) (host_setup.cpp: band_schedule) so a
+// step's operands are ONE coalesced load with an immediate offset, fetched a
+// whole 32-step chunk ahead.  Then z = y / D (IEEE divide) and the mirrored
+// backward pass (row i lives in lane (n-1-i) % M).
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
-constexpr int BAND_CH = 8;
-__global__ __launch_bounds__(64) void band_solve_kernel(
-    int64_t n, int w, const double* __restrict__ lcol, const double* __restrict__ dg,
-    const double* __restrict__ f, double* __restrict__ x) {
-  const int lane = threadIdx.x;
-  const int wq = w > 0 ? w : 1;
-  // ---- forward: L y = f ----
-  double acc = (lane < n) ? f[lane] : 0.0;
-  for (int64_t k0 = 0; k0 < n; k0 += BAND_CH) {
-    double lc[BAND_CH];
+// v_writelane_b32 has no clang builtin on this toolchain.  dst[lane] = uniform
+// value; `lane` is wave-uniform.  (SALU-written lane select, SGPR data operand:
+// no software wait states needed on gfx9-family for this pair.)
+template <int LANE>  // immediate lane select: an SGPR one would be a 2nd constant-bus read
+__device__ __forceinline__ void writelane_f64(double& dst, double uniform_v) {
+  int lo = __double2loint(dst), hi = __double2hiint(dst);
+  const int ulo = __builtin_amdgcn_readfirstlane(__double2loint(uniform_v));
+  const int uhi = __builtin_amdgcn_readfirstlane(__double2hiint(uniform_v));
+  asm volatile("v_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+               : "+v"(lo), "+v"(hi)
+               : "s"(ulo), "s"(uhi), "n"(LANE));
+  dst = __hiloint2double(hi, lo);
+}
+
+constexpr int BAND_CH = 32;  // steps per register-prefetched chunk
+
+struct BandChunk {
+  double lc[BAND_CH];  // lane l < M: its L operand for each of the 32 steps
+  double nx;           // lane i < 32: right-hand side of the row picked up after step i
+};
+
+// FWD: step s handles row s; else row n-1-s.  The schedule is zero-padded to a
+// multiple of 64 steps (+64), so there are no bounds checks on it.
+template <int M, bool FWD>
+__device__ __forceinline__ void band_load(BandChunk& c, int64_t s0, int64_t n, int lane,
+                                          const double* __restrict__ sched,
+                                          const double* __restrict__ rhs) {
+  if (lane < M) {
+    const double* p = sched + s0 * M + lane;
 #pragma unroll
-    for (int i = 0; i < BAND_CH; ++i) {
-      const int64_t k = k0 + i;
-      const int d = (lane - (int)(k & 63)) & 63;
-      lc[i] = (k < n && d >= 1 && d <= w && k + d < n) ? lcol[k * wq + (d - 1)] : 0.0;
-    }
+    for (int i = 0; i < BAND_CH; ++i) c.lc[i] = p[i * M];
+  } else {
 #pragma unroll
-    for (int i = 0; i < BAND_CH; ++i) {
-      const int64_t k = k0 + i;
-      if (k < n) {
-        const int owner = (int)(k & 63);
-        const double yk = readlane_f64(acc, owner);
-        const int d = (lane - owner) & 63;
-        if (d >= 1 && d <= w && k + d < n) acc -= lc[i] * yk;
-        if (lane == owner) {
-          x[k] = yk;
-          acc = (k + 64 < n) ? f[k + 64] : 0.0;
-        }
-      }
-    }
+    for (int i = 0; i < BAND_CH; ++i) c.lc[i] = 0.0;
   }
-  __threadfence_block();
-  // ---- diagonal: z = y / D ----
-  for (int64_t i = lane; i < n; i += 64) x[i] = x[i] / dg[i];
-  __threadfence_block();
-  // ---- backward: L^T x = z; row i collects k = i+w .. i+1 (descending) ----
-  // lane ownership mirrored: row i lives in lane (n-1-i) & 63
-  {
-    const int64_t i0 = n - 1 - lane;
-    acc = (i0 >= 0) ? x[i0] : 0.0;
-  }
-  for (int64_t t0 = 0; t0 < n; t0 += BAND_CH) {
-    double lc[BAND_CH];
-#pragma unroll
-    for (int i = 0; i < BAND_CH; ++i) {
-      const int64_t t = t0 + i;         // t-th step handles k = n-1-t
-      const int64_t k = n - 1 - t;
-      const int d = (lane - (int)(t & 63)) & 63;  // this lane's row is k-d
-      lc[i] = (t < n && d >= 1 && d <= w && k - d >= 0) ? lcol[(k - d) * wq + (d - 1)] : 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < BAND_CH; ++i) {
-      const int64_t t = t0 + i;
-      if (t < n) {
-        const int64_t k = n - 1 - t;
-        const int owner = (int)(t & 63);
-        const double xk = readlane_f64(acc, owner);
-        const int d = (lane - owner) & 63;
-        if (d >= 1 && d <= w && k - d >= 0) acc -= lc[i] * xk;
-        if (lane == owner) {
-          const int64_t nxt = k - 64;   // next row owned by this lane
-          const double z = (nxt >= 0) ? x[nxt] : 0.0;
-          x[k] = xk;
-          acc = z;
-        }
-      }
-    }
+  // after step s0+i its owner lane picks up row s0+i+M; rows past the end read
+  // as 0.0 so that the padded steps broadcast 0.0, never garbage
+  const int64_t s2 = s0 + lane + M;
+  const bool ok = lane < BAND_CH && s2 < n;
+  const double v = rhs[ok ? (FWD ? s2 : n - 1 - s2) : 0];
+  c.nx = ok ? v : 0.0;
+}
+
+// PH = (s0 / 32) % 2 (the owner of step s0+i is lane (PH*32 + i) % M).
+template <int M, int PH, int I>
+__device__ __forceinline__ void band_step(const BandChunk& c, double& acc, double& done) {
+  constexpr int owner = (PH * BAND_CH + I) & (M - 1);
+  const double vk = readlane_f64(acc, owner);
+  acc -= c.lc[I] * vk;  // lc == 0 outside the band and for the owner itself
+  writelane_f64<I>(done, vk);
+  writelane_f64<owner>(acc, readlane_f64(c.nx, I));
+}
+template <int M, int PH, int... I>
+__device__ __forceinline__ void band_step_seq(const BandChunk& c, double& acc, double& done,
+                                              std::integer_sequence<int, I...>) {
+  (band_step<M, PH, I>(c, acc, done), ...);
+}
+template <int M, bool FWD, int PH>
+__device__ __forceinline__ void band_steps(const BandChunk& c, double& acc, int64_t s0,
+                                           int64_t n, int lane, double* __restrict__ x) {
+  double done = 0.0;  // lane i collects the value finished at step s0+i
+  band_step_seq<M, PH>(c, acc, done, std::make_integer_sequence<int, BAND_CH>{});
+  const int64_t s = s0 + lane;
+  if (lane < BAND_CH && s < n) x[FWD ? s : n - 1 - s] = done;
+}
+
+template <int M, bool FWD>
+__device__ __forceinline__ void band_pass(int64_t n, int lane, const double* __restrict__ sched,
+                                          const double* __restrict__ rhs, double* __restrict__ x) {
+  double acc = 0.0;
+  if (lane < M && lane < n) acc = FWD ? rhs[lane] : rhs[n - 1 - lane];
+  BandChunk A, B;
+  band_load<M, FWD>(A, 0, n, lane, sched, rhs);
+  for (int64_t s0 = 0; s0 < n; s0 += 2 * BAND_CH) {  // s0 % 64 == 0
+    band_load<M, FWD>(B, s0 + BAND_CH, n, lane, sched, rhs);
+    band_steps<M, FWD, 0>(A, acc, s0, n, lane, x);
+    band_load<M, FWD>(A, s0 + 2 * BAND_CH, n, lane, sched, rhs);
+    band_steps<M, FWD, 1>(B, acc, s0 + BAND_CH, n, lane, x);
   }
 }
-hipError_t launch_band_solve(int64_t n, int w, const double* lcol, const double* dg,
-                             const double* f, double* x, hipStream_t st) {
+
+// y: scratch vector of n doubles (forward result, then z = y / D).
+template <int M>
+__global__ __launch_bounds__(64) void band_solve_kernel(
+    int64_t n, const double* __restrict__ sched_f, const double* __restrict__ sched_b,
+    const double* __restrict__ dg, const double* __restrict__ f, double* __restrict__ y,
+    double* __restrict__ x) {
+  const int lane = threadIdx.x;
+  band_pass<M, true>(n, lane, sched_f, f, y);           // L y = f
+  __threadfence_block();
+  for (int64_t i = lane; i < n; i += 64) y[i] = y[i] / dg[i];  // z = y / D
+  __threadfence_block();
+  band_pass<M, false>(n, lane, sched_b, y, x);          // L^T x = z
+}
+
+hipError_t launch_band_solve(int64_t n, int m, const double* sched_f, const double* sched_b,
+                             const double* dg, const double* f, double* y, double* x,
+                             hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  if (w > 63) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(64), 0, st, n, w, lcol, dg, f, x);
+  switch (m) {
+    case 4: hipLaunchKernelGGL(band_solve_kernel<4>, dim3(1), dim3(64), 0, st, n, sched_f, sched_b, dg, f, y, x); break;
+    case 8: hipLaunchKernelGGL(band_solve_kernel<8>, dim3(1), dim3(64), 0, st, n, sched_f, sched_b, dg, f, y, x); break;
+    case 16: hipLaunchKernelGGL(band_solve_kernel<16>, dim3(1), dim3(64), 0, st, n, sched_f, sched_b, dg, f, y, x); break;
+    case 32: hipLaunchKernelGGL(band_solve_kernel<32>, dim3(1), dim3(64), 0, st, n, sched_f, sched_b, dg, f, y, x); break;
+    case 64: hipLaunchKernelGGL(band_solve_kernel<64>, dim3(1), dim3(64), 0, st, n, sched_f, sched_b, dg, f, y, x); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

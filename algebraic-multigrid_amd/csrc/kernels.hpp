@@ -17,12 +17,18 @@ hipError_t launch_csr(int mode, int64_t n, int64_t nnz, int max_block_nnz,
                       int max_row_nnz, const int32_t* rowptr, const int32_t* col,
                       const double* val, const double* x, const double* f,
                       double* out, double omega, int64_t diag_shift, hipStream_t st);
+// Same operations on a SELL-64 matrix (64-row panels, lane-interleaved):
+// soff[n/64 + 1] panel offsets, scol/sval padded with col = -1.
+hipError_t launch_sell(int mode, int64_t n, int max_width, const int64_t* soff,
+                       const int32_t* scol, const double* sval, const double* x,
+                       const double* f, double* out, double omega, hipStream_t st);
 // out2[0] = max_block_nnz, out2[1] = max_row_nnz (device int32[2])
 hipError_t launch_csr_shape(int64_t n, const int32_t* rowptr, int32_t* out2,
                             hipStream_t st);
 
+// uH_zero (may be null): coarse solution vector zero-filled in the same pass
 hipError_t launch_linear_restrict(int64_t n_h, int64_t n_H, const double* r, double* fH,
-                                  hipStream_t st);
+                                  double* uH_zero, hipStream_t st);
 hipError_t launch_linear_prolong_add(int64_t n_h, int64_t n_H, const double* uH,
                                      double* uh, hipStream_t st);
 hipError_t launch_add_inplace(int64_t n, const double* x, double* y, hipStream_t st);
@@ -44,7 +50,10 @@ struct LexDev {  // device copy of a LexSchedule
 hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, double omega,
                          hipStream_t st);
 
-hipError_t launch_band_solve(int64_t n, int w, const double* lcol, const double* dg,
-                             const double* f, double* x, hipStream_t st);
+// m: lanes taking part (power of two > half-bandwidth, 4..64); sched_f/sched_b:
+// per-(step, lane) L operands (host_setup: band_schedule); y: scratch, n doubles
+hipError_t launch_band_solve(int64_t n, int m, const double* sched_f, const double* sched_b,
+                             const double* dg, const double* f, double* y, double* x,
+                             hipStream_t st);
 
 }  // namespace amg_hip

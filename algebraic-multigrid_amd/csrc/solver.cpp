@@ -110,6 +110,50 @@ hipError_t upload_csr(const Sparse& M, DevCsr* D) {
   return upload(D->val, M.val.data(), M.val.size());
 }
 
+// A level matrix on the device in one of the two layouts the kernels take.
+struct DevMat {
+  bool sell = false;
+  int64_t n_rows = 0, nnz = 0;
+  DevCsr csr;                 // K-CSR (LDS-staged CSR)
+  int max_width = 0;          // K-SELL (64-row panels, lane-interleaved)
+  int64_t slots = 0;
+  DevMem soff, scol, sval;
+};
+
+int g_default_layout = AMG_HIP_LAYOUT_AUTO;
+
+// layout: AMG_HIP_LAYOUT_*; AUTO takes SELL-64 unless padding exceeds 25 %.
+hipError_t upload_mat(const Sparse& M, int layout, DevMat* D) {
+  D->n_rows = M.n_outer;
+  D->nnz = M.nnz();
+  bool sell = layout == AMG_HIP_LAYOUT_SELL;
+  Sell64 S;
+  if (layout != AMG_HIP_LAYOUT_CSR && M.n_outer < ((int64_t)1 << 31) - 512) {
+    to_sell64(M, &S);
+    if (layout == AMG_HIP_LAYOUT_AUTO) sell = (double)S.slots() <= 1.25 * (double)M.nnz() + 4096.0;
+  } else {
+    sell = false;
+  }
+  D->sell = sell;
+  if (!sell) return upload_csr(M, &D->csr);
+  D->max_width = S.max_width;
+  D->slots = S.slots();
+  hipError_t e;
+  if ((e = upload(D->soff, S.soff.data(), S.soff.size())) != hipSuccess) return e;
+  if ((e = upload(D->scol, S.col.data(), S.col.size())) != hipSuccess) return e;
+  return upload(D->sval, S.val.data(), S.val.size());
+}
+
+hipError_t launch_mat(int mode, const DevMat& A, const double* x, const double* f, double* out,
+                      double omega, hipStream_t st) {
+  if (A.sell)
+    return launch_sell(mode, A.n_rows, A.max_width, A.soff.as<int64_t>(), A.scol.as<int32_t>(),
+                       A.sval.as<double>(), x, f, out, omega, st);
+  const DevCsr& C = A.csr;
+  return launch_csr(mode, C.n_rows, C.nnz, C.max_block_nnz, C.max_row_nnz, C.rowptr(), C.col(),
+                    C.v(), x, f, out, omega, 0, st);
+}
+
 struct LexOnDev {
   LexDev d;
   DevMem row, depth, win_depth, col, val, src;
@@ -145,10 +189,10 @@ struct ColorSet {  // rows of one colour, for the multicolour smoother
 struct Level {
   int64_t n = 0;
   Sparse A_csc;            // host copy, what get_coefficient_matrix returns
-  DevCsr A_rows;           // CSR(A): residual, AMG::Jacobi, SOR
-  DevCsr A_cols_own;       // CSC arrays walked as rows (SpGS & build-side
-  bool symmetric = false;  //   smoothers); aliases A_rows when bitwise equal
-  const DevCsr& A_cols() const { return symmetric ? A_rows : A_cols_own; }
+  DevMat A_rows;           // rows of A: residual, rss
+  DevMat A_cols_own;       // CSC arrays walked as rows (column-as-row smoothers,
+  bool symmetric = false;  //   smoother.hpp:101-117); aliases A_rows when bitwise equal
+  const DevMat& A_cols() const { return symmetric ? A_rows : A_cols_own; }
   DevMem u, f, r, tmp;
   // transfers to level+1 (absent on the coarsest level)
   Sparse P_csc, R_csc;
@@ -171,7 +215,8 @@ struct amg_hip_solver {
   std::vector<Level> lv;
   // coarsest level factor
   int64_t band_n = 0, band_w = 0;
-  DevMem band_l, band_d;
+  int band_m = 0;
+  DevMem band_f, band_b, band_d;
   DevMem scratch;   // 1024 doubles + 1 result
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -210,13 +255,11 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l) {
       return AMG_HIP_OK;
     }
     case AMG_HIP_SM_JACOBI: {
-      const DevCsr& A = L.A_cols();
+      const DevMat& A = L.A_cols();
       double* a = L.u.as<double>();
       double* b = L.tmp.as<double>();
       for (int it = 0; it < iters; ++it) {
-        HIP_TRY(launch_csr(CSR_JACOBI, A.n_rows, A.nnz, A.max_block_nnz, A.max_row_nnz,
-                           A.rowptr(), A.col(), A.v(), a, L.f.as<double>(), b,
-                           s->opt.omega, 0, st));
+        HIP_TRY(launch_mat(CSR_JACOBI, A, a, L.f.as<double>(), b, s->opt.omega, st));
         std::swap(a, b);
       }
       if (iters & 1)  // result sits in tmp: bring it home (keeps the graph static)
@@ -240,10 +283,8 @@ amg_hip_status enqueue_multicolor(amg_hip_solver*, Level&, hipStream_t) {
 
 amg_hip_status enqueue_residual(amg_hip_solver* s, int l) {
   Level& L = s->lv[l];
-  const DevCsr& A = L.A_rows;
-  HIP_TRY(launch_csr(CSR_RESID, A.n_rows, A.nnz, A.max_block_nnz, A.max_row_nnz, A.rowptr(),
-                     A.col(), A.v(), L.u.as<double>(), L.f.as<double>(), L.r.as<double>(),
-                     1.0, 0, s->stream));
+  HIP_TRY(launch_mat(CSR_RESID, L.A_rows, L.u.as<double>(), L.f.as<double>(), L.r.as<double>(),
+                     1.0, s->stream));
   return AMG_HIP_OK;
 }
 
@@ -258,10 +299,11 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
     if (l + 1 != nl) {
       Level& L = s->lv[l];
       Level& C = s->lv[l + 1];
-      HIP_TRY(hipMemsetAsync(C.u.p, 0, sizeof(double) * C.n, st)); // :278
-      if (L.linear && s->opt.stencil_transfers) {                  // :281-282
-        HIP_TRY(launch_linear_restrict(L.n, C.n, L.r.as<double>(), C.f.as<double>(), st));
+      if (L.linear && s->opt.stencil_transfers) {                  // :278 + :281-282
+        HIP_TRY(launch_linear_restrict(L.n, C.n, L.r.as<double>(), C.f.as<double>(),
+                                       C.u.as<double>(), st));
       } else {
+        HIP_TRY(hipMemsetAsync(C.u.p, 0, sizeof(double) * C.n, st)); // :278
         const DevCsr& R = L.R_rows;
         HIP_TRY(launch_csr(CSR_SPMV, R.n_rows, R.nnz, R.max_block_nnz, R.max_row_nnz,
                            R.rowptr(), R.col(), R.v(), L.r.as<double>(), nullptr,
@@ -271,8 +313,9 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
   }
   {                                                                // :287-288
     Level& C = s->lv[nl - 1];
-    HIP_TRY(launch_band_solve(s->band_n, (int)s->band_w, s->band_l.as<double>(),
-                              s->band_d.as<double>(), C.f.as<double>(), C.u.as<double>(), st));
+    HIP_TRY(launch_band_solve(s->band_n, s->band_m, s->band_f.as<double>(),
+                              s->band_b.as<double>(), s->band_d.as<double>(), C.f.as<double>(),
+                              C.tmp.as<double>(), C.u.as<double>(), st));
   }
   for (int l = nl - 2; l >= 0; --l) {                              // :291
     Level& L = s->lv[l];
@@ -357,6 +400,8 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
   if (s->opt.smoother < 0 || s->opt.smoother > AMG_HIP_SM_MULTICOLOR_GS)
     return fail(AMG_HIP_EINVAL, "unknown smoother kind");
   if (s->opt.smoother_iters < 0) return fail(AMG_HIP_EINVAL, "`smoother_iters` must be >= 0");
+  if (s->opt.layout < AMG_HIP_LAYOUT_AUTO || s->opt.layout > AMG_HIP_LAYOUT_SELL)
+    return fail(AMG_HIP_EINVAL, "unknown matrix layout");
   if (s->opt.smoother == AMG_HIP_SM_SOR && (s->opt.omega > 2 || s->opt.omega < 0))
     return fail(AMG_HIP_EINVAL, "`omega` must be in [0, 2] but got omega=" +
                                     std::to_string(s->opt.omega) + "\n");  // smoother.hpp:286-293
@@ -386,8 +431,9 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
   for (int l = 0; l < n_levels; ++l) {
     Level& L = s->lv[l];
     L.symmetric = same_arrays(A_r, L.A_csc);
-    HIP_TRY(upload_csr(A_r, &L.A_rows));
-    if (!L.symmetric) HIP_TRY(upload_csr(L.A_csc, &L.A_cols_own));
+    HIP_TRY(upload_mat(A_r, s->opt.layout, &L.A_rows));
+    if (!L.symmetric && s->opt.smoother >= AMG_HIP_SM_JACOBI)
+      HIP_TRY(upload_mat(L.A_csc, s->opt.layout, &L.A_cols_own));
     HIP_TRY(L.u.alloc(sizeof(double) * L.n));
     HIP_TRY(L.f.alloc(sizeof(double) * L.n));
     HIP_TRY(L.r.alloc(sizeof(double) * L.n));
@@ -455,14 +501,15 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     BandFactor F;
     std::string e = band_factor(s->lv[n_levels - 1].A_csc, (size_t)8 << 30, &F);
     if (!e.empty()) return fail(AMG_HIP_EINVAL, e);
-    if (F.w > 63)
-      return fail(AMG_HIP_EUNSUPPORTED,
-                  "coarsest operator has half-bandwidth " + std::to_string(F.w) +
-                      " > 63 (device band solve limit); use more levels");
+    BandSchedule S;
+    e = band_schedule(F, &S);
+    if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
     s->band_n = F.n;
     s->band_w = F.w;
-    HIP_TRY(upload(s->band_l, F.lcol.data(), F.lcol.size()));
-    HIP_TRY(upload(s->band_d, F.d.data(), F.d.size()));
+    s->band_m = S.m;
+    HIP_TRY(upload(s->band_f, S.sched_f.data(), S.sched_f.size()));
+    HIP_TRY(upload(s->band_b, S.sched_b.data(), S.sched_b.size()));
+    HIP_TRY(upload(s->band_d, S.d.data(), S.d.size()));
   }
   HIP_TRY(s->scratch.alloc(sizeof(double) * 1100));
   compute_bytes(s.get());
@@ -500,6 +547,11 @@ void amg_hip_default_options(amg_hip_options* o) {
   o->device = -1;
   o->use_graph = 1;
   o->stencil_transfers = 1;
+  o->layout = g_default_layout;
+}
+
+void amg_hip_set_default_layout(int32_t layout) {
+  if (layout >= AMG_HIP_LAYOUT_AUTO && layout <= AMG_HIP_LAYOUT_SELL) g_default_layout = layout;
 }
 
 int amg_hip_device_count(void) {
@@ -561,10 +613,8 @@ amg_hip_status amg_hip_rss(amg_hip_solver* s, double* out) {
   amg_hip_status r = set_device(s);
   if (r != AMG_HIP_OK) return r;
   Level& L = s->lv[0];
-  const DevCsr& A = L.A_rows;
-  HIP_TRY(launch_csr(CSR_RSSQ, A.n_rows, A.nnz, A.max_block_nnz, A.max_row_nnz, A.rowptr(),
-                     A.col(), A.v(), L.u.as<double>(), L.f.as<double>(), L.tmp.as<double>(),
-                     1.0, 0, s->stream));
+  HIP_TRY(launch_mat(CSR_RSSQ, L.A_rows, L.u.as<double>(), L.f.as<double>(), L.tmp.as<double>(),
+                     1.0, s->stream));
   double* sc = s->scratch.as<double>();
   HIP_TRY(launch_sum(L.n, L.tmp.as<double>(), sc + 1024, sc, 0, s->stream));
   HIP_TRY(hipMemcpyAsync(out, sc + 1024, sizeof(double), hipMemcpyDeviceToHost, s->stream));
@@ -673,6 +723,38 @@ amg_hip_status amg_hip_cycle_bytes(const amg_hip_solver* s, double* cycle_bytes,
   return AMG_HIP_OK;
 }
 
+amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
+                                          double* avg_ms, double* min_ms) {
+  if (!s || n_launches < 1) return fail(AMG_HIP_EINVAL, "bad argument");
+  if (s->opt.smoother != AMG_HIP_SM_JACOBI)
+    return fail(AMG_HIP_EUNSUPPORTED, "profile_fine_sweep: only for the Jacobi smoother");
+  amg_hip_status r = set_device(s);
+  if (r != AMG_HIP_OK) return r;
+  Level& L = s->lv[0];
+  const DevMat& A = L.A_cols();
+  std::vector<hipEvent_t> ev(2 * (size_t)n_launches);
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  // keep u: sweep u -> tmp only (u itself is never written)
+  for (int i = 0; i < n_launches; ++i) {
+    HIP_TRY(hipEventRecord(ev[2 * i], s->stream));
+    HIP_TRY(launch_mat(CSR_JACOBI, A, L.u.as<double>(), L.f.as<double>(), L.tmp.as<double>(),
+                       s->opt.omega, s->stream));
+    HIP_TRY(hipEventRecord(ev[2 * i + 1], s->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  double sum = 0, mn = 1e30;
+  for (int i = 0; i < n_launches; ++i) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    sum += ms;
+    mn = std::min<double>(mn, ms);
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (avg_ms) *avg_ms = sum / n_launches;
+  if (min_ms) *min_ms = mn;
+  return AMG_HIP_OK;
+}
+
 // ---- stand-alone operations on host arrays -------------------------------------
 amg_hip_status amg_hip_residual(int64_t n, const int32_t* colptr, const int32_t* rowind,
                                 const double* val, const double* u, const double* f,
@@ -685,14 +767,13 @@ amg_hip_status amg_hip_residual(int64_t n, const int32_t* colptr, const int32_t*
   std::string v = validate(A, "A");
   if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
   Sparse Ar = transpose(A);
-  DevCsr D;
+  DevMat D;
   DevMem du, df, dr;
-  HIP_TRY(upload_csr(Ar, &D));
+  HIP_TRY(upload_mat(Ar, g_default_layout, &D));
   HIP_TRY(upload(du, u, (size_t)n));
   HIP_TRY(upload(df, f, (size_t)n));
   HIP_TRY(dr.alloc(sizeof(double) * n));
-  HIP_TRY(launch_csr(CSR_RESID, n, D.nnz, D.max_block_nnz, D.max_row_nnz, D.rowptr(), D.col(),
-                     D.v(), du.as<double>(), df.as<double>(), dr.as<double>(), 1.0, 0, nullptr));
+  HIP_TRY(launch_mat(CSR_RESID, D, du.as<double>(), df.as<double>(), dr.as<double>(), 1.0, nullptr));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(r, dr.p, sizeof(double) * n, hipMemcpyDeviceToHost));
   return AMG_HIP_OK;
@@ -709,14 +790,12 @@ amg_hip_status amg_hip_spmv(int64_t rows, int64_t cols, const int32_t* colptr,
   std::string e = validate(M, "M");
   if (!e.empty()) return fail(AMG_HIP_EINVAL, e);
   Sparse Mr = transpose(M);
-  DevCsr D;
+  DevMat D;
   DevMem dv, dout;
-  HIP_TRY(upload_csr(Mr, &D));
+  HIP_TRY(upload_mat(Mr, g_default_layout, &D));
   HIP_TRY(upload(dv, v, (size_t)cols));
   HIP_TRY(dout.alloc(sizeof(double) * rows));
-  HIP_TRY(launch_csr(CSR_SPMV, rows, D.nnz, D.max_block_nnz, D.max_row_nnz, D.rowptr(),
-                     D.col(), D.v(), dv.as<double>(), nullptr, dout.as<double>(), 1.0, 0,
-                     nullptr));
+  HIP_TRY(launch_mat(CSR_SPMV, D, dv.as<double>(), nullptr, dout.as<double>(), 1.0, nullptr));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * rows, hipMemcpyDeviceToHost));
   return AMG_HIP_OK;
@@ -729,7 +808,7 @@ amg_hip_status amg_hip_linear_restrict(int64_t n_h, int64_t n_H, const double* r
   DevMem dr, df;
   HIP_TRY(upload(dr, r, (size_t)n_h));
   HIP_TRY(df.alloc(sizeof(double) * n_H));
-  HIP_TRY(launch_linear_restrict(n_h, n_H, dr.as<double>(), df.as<double>(), nullptr));
+  HIP_TRY(launch_linear_restrict(n_h, n_H, dr.as<double>(), df.as<double>(), nullptr, nullptr));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(f_H, df.p, sizeof(double) * n_H, hipMemcpyDeviceToHost));
   return AMG_HIP_OK;
@@ -760,15 +839,14 @@ amg_hip_status amg_hip_rss_host(int64_t n, const int32_t* colptr, const int32_t*
   std::string v = validate(A, "A");
   if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
   Sparse Ar = transpose(A);
-  DevCsr D;
+  DevMat D;
   DevMem du, db, dt, sc;
-  HIP_TRY(upload_csr(Ar, &D));
+  HIP_TRY(upload_mat(Ar, g_default_layout, &D));
   HIP_TRY(upload(du, u, (size_t)n));
   HIP_TRY(upload(db, b, (size_t)n));
   HIP_TRY(dt.alloc(sizeof(double) * n));
   HIP_TRY(sc.alloc(sizeof(double) * 1100));
-  HIP_TRY(launch_csr(CSR_RSSQ, n, D.nnz, D.max_block_nnz, D.max_row_nnz, D.rowptr(), D.col(),
-                     D.v(), du.as<double>(), db.as<double>(), dt.as<double>(), 1.0, 0, nullptr));
+  HIP_TRY(launch_mat(CSR_RSSQ, D, du.as<double>(), db.as<double>(), dt.as<double>(), 1.0, nullptr));
   HIP_TRY(launch_sum(n, dt.as<double>(), sc.as<double>() + 1024, sc.as<double>(), 0, nullptr));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, sc.as<double>() + 1024, sizeof(double), hipMemcpyDeviceToHost));
@@ -788,14 +866,18 @@ amg_hip_status amg_hip_coarse_solve(int64_t n, const int32_t* colptr, const int3
   std::string e = band_factor(A, (size_t)8 << 30, &F);
   if (!e.empty()) return fail(AMG_HIP_EINVAL, e);
   if (halfbw) *halfbw = F.w;
-  if (F.w > 63) return fail(AMG_HIP_EUNSUPPORTED, "half-bandwidth > 63");
-  DevMem dl, dd, df, dx;
-  HIP_TRY(upload(dl, F.lcol.data(), F.lcol.size()));
-  HIP_TRY(upload(dd, F.d.data(), F.d.size()));
+  BandSchedule S;
+  e = band_schedule(F, &S);
+  if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
+  DevMem dsf, dsb, dd, df, dy, dx;
+  HIP_TRY(upload(dsf, S.sched_f.data(), S.sched_f.size()));
+  HIP_TRY(upload(dsb, S.sched_b.data(), S.sched_b.size()));
+  HIP_TRY(upload(dd, S.d.data(), S.d.size()));
   HIP_TRY(upload(df, f, (size_t)n));
+  HIP_TRY(dy.alloc(sizeof(double) * n));
   HIP_TRY(dx.alloc(sizeof(double) * n));
-  HIP_TRY(launch_band_solve(n, (int)F.w, dl.as<double>(), dd.as<double>(), df.as<double>(),
-                            dx.as<double>(), nullptr));
+  HIP_TRY(launch_band_solve(n, S.m, dsf.as<double>(), dsb.as<double>(), dd.as<double>(),
+                            df.as<double>(), dy.as<double>(), dx.as<double>(), nullptr));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(x, dx.p, sizeof(double) * n, hipMemcpyDeviceToHost));
   return AMG_HIP_OK;
@@ -819,12 +901,12 @@ amg_hip_status amg_hip_smooth(int32_t kind, int64_t n, const int32_t* colptr,
   std::string v = validate(A, "A");
   if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
   Sparse Ar = transpose(A);
-  DevCsr Drows;  // CSR(A) for rss and the row-addressed smoothers
-  DevCsr Dcols;  // CSC arrays as rows
+  DevMat Drows;  // rows of A: rss
+  DevMat Dcols;  // CSC arrays as rows: true Jacobi
   const bool sym = same_arrays(A, Ar);
-  HIP_TRY(upload_csr(Ar, &Drows));
-  if (!sym) HIP_TRY(upload_csr(A, &Dcols));
-  const DevCsr& Dc = sym ? Drows : Dcols;
+  HIP_TRY(upload_mat(Ar, g_default_layout, &Drows));
+  if (!sym) HIP_TRY(upload_mat(A, g_default_layout, &Dcols));
+  const DevMat& Dc = sym ? Drows : Dcols;
   DevMem du, db, dt, sc;
   HIP_TRY(upload(du, u, (size_t)n));
   HIP_TRY(upload(db, b, (size_t)n));
@@ -861,15 +943,12 @@ amg_hip_status amg_hip_smooth(int32_t kind, int64_t n, const int32_t* colptr,
     } else if (kind == AMG_HIP_SM_SOR) {
       HIP_TRY(launch_gs_lex(Lf.d, db.as<double>(), cur, 2, omega, nullptr));
     } else {
-      HIP_TRY(launch_csr(CSR_JACOBI, n, Dc.nnz, Dc.max_block_nnz, Dc.max_row_nnz, Dc.rowptr(),
-                         Dc.col(), Dc.v(), cur, db.as<double>(), alt, omega, 0, nullptr));
+      HIP_TRY(launch_mat(CSR_JACOBI, Dc, cur, db.as<double>(), alt, omega, nullptr));
       std::swap(cur, alt);
     }
     iter += 1;
     if (check && every != 0 && iter % every == 0) {
-      HIP_TRY(launch_csr(CSR_RSSQ, n, Drows.nnz, Drows.max_block_nnz, Drows.max_row_nnz,
-                         Drows.rowptr(), Drows.col(), Drows.v(), cur, db.as<double>(), alt, 1.0,
-                         0, nullptr));
+      HIP_TRY(launch_mat(CSR_RSSQ, Drows, cur, db.as<double>(), alt, 1.0, nullptr));
       HIP_TRY(launch_sum(n, alt, sc.as<double>() + 1024, sc.as<double>(), 0, nullptr));
       HIP_TRY(hipDeviceSynchronize());
       HIP_TRY(hipMemcpy(&error, sc.as<double>() + 1024, sizeof(double), hipMemcpyDeviceToHost));

@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- V-cycles/s of the MI355X-native multigrid V-cycle.
+
+Workload (BASELINE.json metric / configs[2]): 2-D 5-point Poisson 4096 x 4096
+(A = Grid::laplacian, b = Grid::rhs, u0 = 0), true (two-buffer) Jacobi smoother,
+2 sweeps pre + 2 post on every level, 16-level hierarchy (coarsest 511 dofs),
+fp64.  One "step" = one vcycle() (multigrid.hpp:263-305), rss excluded.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1: one process, one GPU.  N > 1: launched by torch.distributed.run, one rank
+per GPU, row-block sharded hierarchy with RCCL halo exchange (see
+algebraic-multigrid_amd/dist_vcycle.py); fixed global problem => strong scaling.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "algebraic-multigrid_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def n_levels_for(n, coarsest_max=511):
+    """Smallest level count whose coarsest level has <= coarsest_max dofs
+    (n_H = (n_h+1)/2 - 1, multigrid.hpp:127-130)."""
+    dofs, levels = n * n, 1
+    while dofs > coarsest_max:
+        dofs = (dofs + 1) // 2 - 1
+        levels += 1
+    return levels
+
+
+def cpu_baseline(args):
+    """The CPU oracle (Eigen-order restatement of the reference, 1 thread -- the
+    reference is serial) timed on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    n = args.cpu_n
+    L = n_levels_for(n)
+    A, b = O.laplacian(n), O.rhs(n)
+    mg = O.Multigrid(A, b, L, smoother=O.SM_TRUE_JACOBI, smoother_iters=args.sweeps,
+                     omega=args.omega)
+    mg.time_vcycles(1)  # warm-up
+    reps = args.cpu_cycles
+    times = sorted(mg.time_vcycles(1) for _ in range(reps))
+    med = times[len(times) // 2]
+    scale = (n * n) / float(args.n * args.n)   # V-cycle cost is linear in the dofs
+    return {
+        "value": (1.0 / med) * scale,
+        "unit": "V-cycles/s",
+        "cores": 1,
+        "host_cores": os.cpu_count(),
+        "kind": "port",
+        "sample": (f"{reps} vcycle() calls (median) of the CPU oracle on the {n}x{n} instance of "
+                   f"the same workload ({L} levels, same smoother), rate scaled by "
+                   f"{n * n}/{args.n * args.n} dofs to the {args.n}x{args.n} problem; "
+                   f"measured {1.0 / med:.3f} V-cycles/s at {n}x{n}"),
+    }
+
+
+def run_single(args):
+    import amg_ctypes as amg
+    if amg.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device (libamg_hip.so has no CPU fallback)")
+    t0 = time.time()
+    colptr, rowind, val = amg.laplacian(args.n)
+    b = amg.rhs(args.n)
+    L = args.levels or n_levels_for(args.n)
+    mg = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_JACOBI,
+                       smoother_iters=args.sweeps, omega=args.omega, use_graph=not args.no_graph)
+    setup_s = time.time() - t0
+    del colptr, rowind, val
+    mg.vcycle(args.warmup)
+    mg.sync()
+    rss0 = mg.rss()   # after the warm-up cycles (the first cycle from u=0 raises rss)
+    t1 = time.perf_counter()
+    mg.vcycle(args.steps)
+    mg.sync()
+    dt = time.perf_counter() - t1
+    # dominant kernel: level-0 Jacobi sweep, HIP events on the solver's stream
+    avg_ms, min_ms = mg.profile_fine_sweep(args.profile_launches)
+    cyc_bytes, sweep_bytes = mg.cycle_bytes()
+    rss = mg.rss()
+    if args.warmup >= 1 and not (rss < rss0):
+        raise SystemExit(f"V-cycle iteration is not converging (rss {rss0:.3e} -> {rss:.3e})")
+    sizes = [mg.get_n_dofs(l) for l in range(L)]
+    achieved = sweep_bytes / (avg_ms * 1e-3) / 1e9
+    out = {
+        "metric": "V-cycles/sec, 2D Poisson N=4096^2 (fine-grid smoother HBM GB/s under roofline)",
+        "value": args.steps / dt,
+        "unit": "V-cycles/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"2D 5-point Poisson {args.n}x{args.n} (Grid::laplacian/rhs), true Jacobi "
+                         f"smoother omega={args.omega} {args.sweeps}+{args.sweeps} sweeps, "
+                         f"{L}-level V-cycle, coarsest {sizes[-1]} dofs, fp64, 1xMI355X"),
+            "n": args.n, "levels": L, "smoother": "jacobi", "omega": args.omega,
+            "sweeps": args.sweeps, "graph": not args.no_graph,
+            "cycle_algorithmic_bytes": cyc_bytes, "cycle_GBps": cyc_bytes / (dt / args.steps) / 1e9,
+            "setup_seconds": setup_s, "rss_after_warmup": rss0, "rss_after_steps": rss,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "sell_kernel<CSR_JACOBI,5> (level-0 Jacobi sweep, SELL-64 panels)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": sweep_bytes,
+            "avg_launch_ms": avg_ms,
+            "min_launch_ms": min_ms,
+            "launches_timed": args.profile_launches,
+        },
+    }
+    mg.close()
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=4096, help="grid points per direction")
+    ap.add_argument("--levels", type=int, default=0, help="0 = coarsest <= 511 dofs")
+    ap.add_argument("--omega", type=float, default=0.6,
+                    help="Jacobi relaxation; must stay below 2/lambda_max(D^-1 A) ~ 0.67 on the "
+                         "reference's flat-index Galerkin levels (DESIGN.md)")
+    ap.add_argument("--sweeps", type=int, default=2, help="Jacobi sweeps per smooth() call")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-n", type=int, default=2048, help="grid of the CPU baseline sample")
+    ap.add_argument("--cpu-cycles", type=int, default=5)
+    ap.add_argument("--profile-launches", type=int, default=40)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        import dist_vcycle
+        out = dist_vcycle.bench(args)
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        return
+    out = run_single(args)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,13 @@ typedef enum {
   AMG_HIP_SM_MULTICOLOR_GS = 4  /* symmetric multicolour Gauss-Seidel           */
 } amg_hip_smoother;
 
+/* Device layout of the level matrices (results are bit-identical in both).   */
+typedef enum {
+  AMG_HIP_LAYOUT_AUTO = 0, /* SELL-64 unless its padding exceeds 25 %            */
+  AMG_HIP_LAYOUT_CSR = 1,  /* plain CSR, LDS-staged kernel (K-CSR)               */
+  AMG_HIP_LAYOUT_SELL = 2  /* CSR sliced in 64-row lane-interleaved panels       */
+} amg_hip_layout;
+
 /* Options of amg_hip_create.  Zero-initialise, then amg_hip_default_options. */
 typedef struct {
   int32_t smoother;        /* amg_hip_smoother; default AMG_HIP_SM_SPGS         */
@@ -65,13 +72,18 @@ typedef struct {
   int32_t stencil_transfers; /* 1 (default): when P/R are the built-in
                               LinearInterpolator, use the matrix-free stride-2
                               kernels (bit-identical to the CSR path)           */
-  int32_t reserved[8];
+  int32_t layout;          /* amg_hip_layout of the level matrices on the device  */
+  int32_t reserved[7];
 } amg_hip_options;
 
 typedef struct amg_hip_solver amg_hip_solver; /* opaque; owns device memory    */
 
 const char* amg_hip_last_error(void);
 void amg_hip_default_options(amg_hip_options* o);
+
+/* Layout used by amg_hip_default_options and by the stand-alone host-array
+ * operations below (process-wide; tests flip it to run both kernels).         */
+void amg_hip_set_default_layout(int32_t layout);
 
 /* Number of usable HIP devices (0 when none; never fails). */
 int amg_hip_device_count(void);
@@ -158,6 +170,15 @@ amg_hip_status amg_hip_get_colors(const amg_hip_solver* s, int32_t level,
  * formulae) and the per-sweep bytes of level 0; used by bench.py.             */
 amg_hip_status amg_hip_cycle_bytes(const amg_hip_solver* s, double* cycle_bytes,
                                    double* fine_sweep_bytes);
+
+/* Measurement hook for bench.py: launches the level-0 smoother sweep kernel
+ * (the dominant kernel of a V-cycle) n_launches times back to back on the
+ * solver's own stream, each launch bracketed by a pair of HIP events on that
+ * stream, and returns the average / minimum launch duration in milliseconds.
+ * Only for AMG_HIP_SM_JACOBI (one launch = one sweep over level 0); the level-0
+ * solution is restored afterwards.                                            */
+amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
+                                          double* avg_ms, double* min_ms);
 
 /* ---- stand-alone plug-in operations on host arrays (run on the device) -----
  * SmootherBase::smooth(A, u, b), smoother.hpp:63-65, for the built-in kinds.

@@ -18,6 +18,15 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
+@pytest.fixture(autouse=True, params=["csr", "sell"])
+def layout(request, amg):
+    """Every test runs twice: level matrices as plain CSR (LDS-staged K-CSR
+    kernel) and as SELL-64 panels (K-SELL).  Results must be bit-identical."""
+    amg.set_default_layout(amg.LAYOUT_CSR if request.param == "csr" else amg.LAYOUT_SELL)
+    yield request.param
+    amg.set_default_layout(amg.LAYOUT_AUTO)
+
+
 def csc(A):
     return A.colptr, A.rowind, A.val
 
@@ -326,12 +335,13 @@ def test_custom_interpolator_path(amg, oracle):
     assert np.array_equal(mg2.get_soln(0), ref.get_vec(0, "u"))
     mg.close()
     mg2.close()
-    # full-weighting style R = 0.5 * P^T (not the built-in): still converges
+    # R = 0.5 * P^T (not the built-in): generic CSR transfer kernels.  Galerkin
+    # A_H and f_H both scale by 0.5, so the coarse correction -- and the whole
+    # iteration -- is the same up to rounding.
     tr2 = [((P[0], P[1], P[2]), (R[0], R[1], 0.5 * R[2])) for (P, R) in tr]
-    mg3 = amg.Multigrid(*csc(A), b, L, transfers=tr2, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.8)
-    r0 = mg3.rss()
-    mg3.vcycle(5)
-    assert mg3.rss() < 1e-2 * r0
+    mg3 = amg.Multigrid(*csc(A), b, L, transfers=tr2)
+    mg3.vcycle(3)
+    assert rel(mg3.get_soln(0), ref.get_vec(0, "u")) < 1e-12
     mg3.close()
 
 
@@ -372,8 +382,8 @@ def test_config2_like_parity_1e10(amg, oracle):
 
 
 def test_3d_7point_vcycle(amg, oracle):
-    # BASELINE config 5 shape at 24^3: build-side generator, oracle twin only
-    n, L = 24, 4
+    # BASELINE config 5 shape at 16^3: build-side generator, oracle twin only
+    n, L = 16, 5
     A, b = oracle.laplacian(n, dim=3), oracle.rhs(n, dim=3)
     ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.8)
     mg = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.8)
