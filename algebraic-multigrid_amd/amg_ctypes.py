@@ -34,7 +34,7 @@ class Options(C.Structure):
     _fields_ = [("smoother", C.c_int32), ("smoother_iters", C.c_int32),
                 ("omega", C.c_double), ("device", C.c_int32), ("use_graph", C.c_int32),
                 ("stencil_transfers", C.c_int32), ("layout", C.c_int32),
-                ("reserved", C.c_int32 * 7)]
+                ("host_only", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 # name -> (restype, argtypes).  Must list EVERY symbol include/amg_hip.h declares
@@ -65,6 +65,8 @@ _SIGS = {
     "amg_hip_get_transfer": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i32p, _f64p]),
     "amg_hip_get_vec": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p]),
     "amg_hip_set_vec": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p]),
+    "amg_hip_copy_vec_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "amg_hip_zero_vec": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "amg_hip_coarse_halfbw": (C.c_int64, [C.c_void_p]),
     "amg_hip_get_colors": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p]),
     "amg_hip_cycle_bytes": (C.c_int, [C.c_void_p, _f64p, _f64p]),
@@ -169,7 +171,7 @@ class Multigrid:
     def __init__(self, colptr, rowind, val, b, n_levels, smoother=SM_SPGS,
                  smoother_iters=1, omega=1.0, tolerance=1e-9, compute_error_every_n_iters=10,
                  n_iters=100, device=-1, use_graph=True, stencil_transfers=True,
-                 transfers=None, layout=None):
+                 transfers=None, layout=None, host_only=False):
         # multigrid.hpp:165-178 (same checks, same order)
         if compute_error_every_n_iters > n_iters:
             raise ValueError("`compute_error_every_n_iters` must be leq to `n_iters`, got "
@@ -188,6 +190,7 @@ class Multigrid:
         o.device, o.use_graph, o.stencil_transfers = device, int(use_graph), int(stencil_transfers)
         if layout is not None:
             o.layout = layout
+        o.host_only = int(host_only)
         h = C.c_void_p()
         if transfers is None:
             st = lib().amg_hip_create(n, _p32(colptr), _p32(rowind), _p64(val), _p64(b),
@@ -273,6 +276,13 @@ class Multigrid:
         v = _a64(v)
         assert v.size == self.get_n_dofs(level)
         _chk(lib().amg_hip_set_vec(self._h, level, {"u": 0, "f": 1, "r": 2}[which], _p64(v)))
+
+    def copy_vec_dev(self, level, which, dev_ptr, to_solver):
+        _chk(lib().amg_hip_copy_vec_dev(self._h, level, {"u": 0, "f": 1, "r": 2}[which],
+                                        C.c_void_p(dev_ptr), int(to_solver)))
+
+    def zero_vec(self, level, which):
+        _chk(lib().amg_hip_zero_vec(self._h, level, {"u": 0, "f": 1, "r": 2}[which]))
 
     def get_tolerance(self):
         return self.tolerance

@@ -353,6 +353,8 @@ amg_hip_status ensure_graph(amg_hip_solver* s) {
 }
 
 amg_hip_status set_device(const amg_hip_solver* s) {
+  if (s->opt.host_only)
+    return fail(AMG_HIP_EINVAL, "solver was created with host_only = 1: no device state");
   HIP_TRY(hipSetDevice(s->device));
   return AMG_HIP_OK;
 }
@@ -405,17 +407,20 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
   if (s->opt.smoother == AMG_HIP_SM_SOR && (s->opt.omega > 2 || s->opt.omega < 0))
     return fail(AMG_HIP_EINVAL, "`omega` must be in [0, 2] but got omega=" +
                                     std::to_string(s->opt.omega) + "\n");  // smoother.hpp:286-293
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(AMG_HIP_EHIP, "no HIP device available (this library has no CPU fallback)");
-  if (s->opt.device >= 0) {
-    if (s->opt.device >= ndev) return fail(AMG_HIP_EINVAL, "device ordinal out of range");
-    s->device = s->opt.device;
-  } else {
-    HIP_TRY(hipGetDevice(&s->device));
+  const bool dev = !s->opt.host_only;
+  if (dev) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      return fail(AMG_HIP_EHIP, "no HIP device available (this library has no CPU fallback)");
+    if (s->opt.device >= 0) {
+      if (s->opt.device >= ndev) return fail(AMG_HIP_EINVAL, "device ordinal out of range");
+      s->device = s->opt.device;
+    } else {
+      HIP_TRY(hipGetDevice(&s->device));
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   }
-  HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
 
   const int nt = host_threads();
   s->lv.resize(n_levels);
@@ -431,6 +436,7 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
   for (int l = 0; l < n_levels; ++l) {
     Level& L = s->lv[l];
     L.symmetric = same_arrays(A_r, L.A_csc);
+    if (dev) {
     HIP_TRY(upload_mat(A_r, s->opt.layout, &L.A_rows));
     if (!L.symmetric && s->opt.smoother >= AMG_HIP_SM_JACOBI)
       HIP_TRY(upload_mat(L.A_csc, s->opt.layout, &L.A_cols_own));
@@ -460,6 +466,7 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     } else if (s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS) {
       greedy_coloring(L.A_csc, &L.color, &L.n_colors);
     }
+    }  // dev
     if (l + 1 == n_levels) break;
     // ---- transfer operators for level l -> l+1 ----
     const int64_t n_h = L.n;
@@ -481,8 +488,10 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     }
     Sparse P_r = transpose(L.P_csc);  // CSR(P)
     Sparse R_r = transpose(L.R_csc);  // CSR(R)
-    HIP_TRY(upload_csr(P_r, &L.P_rows));
-    HIP_TRY(upload_csr(R_r, &L.R_rows));
+    if (dev) {
+      HIP_TRY(upload_csr(P_r, &L.P_rows));
+      HIP_TRY(upload_csr(R_r, &L.R_rows));
+    }
     // Galerkin (multigrid.hpp:219-223), row-major, Eigen's summation order
     Sparse AH_r = galerkin_csr(R_r, A_r, P_r, nt);
     Level& C = s->lv[l + 1];
@@ -492,6 +501,11 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     A_r.idx.swap(AH_r.idx);
     A_r.val.swap(AH_r.val);
     A_r.n_outer = A_r.n_inner = n_H;
+  }
+  if (!dev) {
+    compute_bytes(s.get());
+    *out = s.release();
+    return AMG_HIP_OK;
   }
   // rhs / initial state (multigrid.hpp:196-204)
   HIP_TRY(hipMemcpy(s->lv[0].f.p, b, sizeof(double) * n, hipMemcpyHostToDevice));
@@ -582,8 +596,10 @@ amg_hip_status amg_hip_create_custom(int64_t n, const int32_t* colptr, const int
 
 void amg_hip_destroy(amg_hip_solver* s) {
   if (!s) return;
-  (void)hipSetDevice(s->device);
-  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (!s->opt.host_only) {
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+  }
   delete s;
 }
 
@@ -604,7 +620,35 @@ amg_hip_status amg_hip_vcycle(amg_hip_solver* s) { return amg_hip_vcycles(s, 1);
 
 amg_hip_status amg_hip_sync(amg_hip_solver* s) {
   if (!s) return fail(AMG_HIP_EINVAL, "null solver");
+  amg_hip_status r = set_device(s);
+  if (r != AMG_HIP_OK) return r;
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_copy_vec_dev(amg_hip_solver* s, int32_t level, int32_t which,
+                                    void* dev_ptr, int32_t to_solver) {
+  if (!s || !dev_ptr || level < 0 || level >= (int32_t)s->lv.size() || which < 0 || which > 2)
+    return fail(AMG_HIP_EINVAL, "bad argument");
+  amg_hip_status r = set_device(s);
+  if (r != AMG_HIP_OK) return r;
+  Level& L = s->lv[level];
+  void* v = which == 0 ? L.u.p : (which == 1 ? L.f.p : L.r.p);
+  if (to_solver)
+    HIP_TRY(hipMemcpyAsync(v, dev_ptr, sizeof(double) * L.n, hipMemcpyDeviceToDevice, s->stream));
+  else
+    HIP_TRY(hipMemcpyAsync(dev_ptr, v, sizeof(double) * L.n, hipMemcpyDeviceToDevice, s->stream));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_zero_vec(amg_hip_solver* s, int32_t level, int32_t which) {
+  if (!s || level < 0 || level >= (int32_t)s->lv.size() || which < 0 || which > 2)
+    return fail(AMG_HIP_EINVAL, "bad argument");
+  amg_hip_status r = set_device(s);
+  if (r != AMG_HIP_OK) return r;
+  Level& L = s->lv[level];
+  void* v = which == 0 ? L.u.p : (which == 1 ? L.f.p : L.r.p);
+  HIP_TRY(hipMemsetAsync(v, 0, sizeof(double) * L.n, s->stream));
   return AMG_HIP_OK;
 }
 
@@ -688,6 +732,7 @@ static DevMem* pick_vec(amg_hip_solver* s, int32_t level, int32_t which) {
 amg_hip_status amg_hip_get_vec(amg_hip_solver* s, int32_t level, int32_t which, double* out) {
   DevMem* m = pick_vec(s, level, which);
   if (!m || !out) return fail(AMG_HIP_EINVAL, "bad level / vector selector");
+  if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "host_only solver has no vectors");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipMemcpy(out, m->p, sizeof(double) * s->lv[level].n, hipMemcpyDeviceToHost));
@@ -697,6 +742,7 @@ amg_hip_status amg_hip_set_vec(amg_hip_solver* s, int32_t level, int32_t which,
                                const double* in) {
   DevMem* m = pick_vec(s, level, which);
   if (!m || !in) return fail(AMG_HIP_EINVAL, "bad level / vector selector");
+  if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "host_only solver has no vectors");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipMemcpy(m->p, in, sizeof(double) * s->lv[level].n, hipMemcpyHostToDevice));

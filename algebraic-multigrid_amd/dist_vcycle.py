@@ -1,0 +1,527 @@
+"""Row-block sharded V-cycle: one process per GPU, torch.distributed (backend
+"nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Scope: the 5-point Poisson hierarchy is banded in the flat dof
+index, so every level is cut into contiguous row blocks, one per rank:
+
+  level 0   rank g owns rows [g*n0/G, (g+1)*n0/G)
+  level l+1 rank g owns the coarse dofs j whose C-point 2j+1 it owns on level l,
+            i.e. [floor(s/2), floor(e/2))
+
+Exchanges (the only collectives on the data path):
+  * halo: before every Jacobi sweep and before the residual each rank swaps the
+    boundary unknowns its neighbours' rows reference (width = the level's half
+    bandwidth m_l+1) with rank-1 / rank+1 -- grouped isend/irecv, KiB-sized;
+  * restriction / prolongation need one remote entry per side (width-1 halo);
+  * when a level gets small (rows/rank below `agglomerate_rows`) its right-hand
+    side is all-gathered and every rank runs the rest of the V-cycle redundantly
+    as an ordinary single-GPU solver on the sub-hierarchy (the C ABI solver with
+    its hipGraph), then keeps its slice of the correction;
+  * rss: all_reduce(SUM) of one fp64.
+
+The smoother is the true (two-buffer) Jacobi -- the lexicographic reference
+smoother is a cross-rank sequential recurrence and does not shard.
+Per-row arithmetic is the single-GPU kernels' (same CSR kernels, same column
+order), so the G-rank result equals the 1-rank result bit for bit; the CPU
+tests (tests/test_dist_gloo.py) check exactly that with a numpy backend.
+
+All compute goes through a `backend` object: HipBackend (torch device tensors +
+the C ABI's device-pointer launchers) in production; tests pass their own.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+# ----------------------------------------------------------------- partition ---
+def row_bounds(n, world):
+    """Level-0 row blocks: rank g owns [bounds[g], bounds[g+1])."""
+    return [n * g // world for g in range(world + 1)]
+
+
+def coarse_bounds(bounds, n_H):
+    """Coarse dof j lives with the owner of fine dof 2j+1 (its C-point)."""
+    out = [min(b // 2, n_H) for b in bounds]
+    out[0] = 0
+    out[-1] = n_H
+    return out
+
+
+class LocalMatrix:
+    """Rows [s, e) of a global CSR matrix with columns renumbered into the
+    rank's halo-extended vector [c_lo .. c_hi]."""
+
+    def __init__(self, rowptr, col, val, s, e, c_lo=None, c_hi=None):
+        p0, p1 = int(rowptr[s]), int(rowptr[e])
+        self.n_rows = e - s
+        self.rowptr = (rowptr[s:e + 1] - p0).astype(np.int32)
+        gcol = col[p0:p1]
+        self.val = np.ascontiguousarray(val[p0:p1], dtype=np.float64)
+        if c_lo is None:
+            c_lo = int(gcol.min()) if gcol.size else s
+            c_hi = int(gcol.max()) if gcol.size else e - 1
+            c_lo, c_hi = min(c_lo, s), max(c_hi, e - 1)
+        self.c_lo, self.c_hi = c_lo, c_hi
+        self.col = (gcol - c_lo).astype(np.int32)
+        self.nnz = int(self.col.size)
+        self.halo_lo = s - c_lo          # entries needed from lower ranks
+        self.halo_hi = c_hi - (e - 1)    # entries needed from higher ranks
+        self.diag_shift = s - c_lo       # local row i has its diagonal at column i + shift
+
+
+def linear_R_rows(cs, ce, n_h, s_fine):
+    """CSR rows [cs, ce) of R = P^T (interpolator.hpp:106-134): row j =
+    {0.5, 1.0, 0.5} at fine columns {2j, 2j+1, 2j+2} (< n_h).  Columns are local
+    to the fine residual vector extended by ONE entry each side: index = c - (s_fine-1)."""
+    j = np.arange(cs, ce, dtype=np.int64)
+    cols = np.stack([2 * j, 2 * j + 1, 2 * j + 2], 1)
+    vals = np.tile(np.array([0.5, 1.0, 0.5]), (j.size, 1))
+    keep = cols < n_h
+    cnt = keep.sum(1)
+    rowptr = np.zeros(j.size + 1, np.int32)
+    np.cumsum(cnt, out=rowptr[1:])
+    return rowptr, (cols[keep] - (s_fine - 1)).astype(np.int32), vals[keep].astype(np.float64)
+
+
+def linear_P_rows(s, e, n_H, cs):
+    """CSR rows [s, e) of P: odd i=2j+1 -> {1.0 @ j}; even i=2j -> {0.5 @ j-1,
+    0.5 @ j} (ascending column, entries outside [0, n_H) dropped).  Columns are
+    local to the coarse vector extended by ONE entry each side: index = j - (cs-1)."""
+    i = np.arange(s, e, dtype=np.int64)
+    j = i // 2
+    odd = (i & 1) == 1
+    c0 = np.where(odd, j, j - 1)
+    c1 = j
+    v0 = np.where(odd, 1.0, 0.5)
+    k0 = (c0 >= 0) & (c0 < n_H)
+    k1 = (~odd) & (c1 < n_H)
+    cols = np.stack([c0, c1], 1)
+    vals = np.stack([v0, np.full(i.size, 0.5)], 1)
+    keep = np.stack([k0, k1], 1)
+    cnt = keep.sum(1)
+    rowptr = np.zeros(i.size + 1, np.int32)
+    np.cumsum(cnt, out=rowptr[1:])
+    return rowptr, (cols[keep] - (cs - 1)).astype(np.int32), vals[keep].astype(np.float64)
+
+
+# ------------------------------------------------------------------- backend ---
+class HipBackend:
+    """torch device tensors + libamg_hip.so device-pointer launchers."""
+
+    def __init__(self, device):
+        import amg_ctypes as amg
+        self.amg = amg
+        self.lib = amg.lib()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+
+    def stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def vec(self, n):
+        return torch.zeros(max(n, 1), dtype=torch.float64, device=self.device)[:n]
+
+    def from_numpy(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy()
+
+    def matrix(self, rowptr, col, val):
+        mb, mr = self.amg.csr_shape(rowptr)
+        m = {"n": rowptr.size - 1, "nnz": int(col.size), "mb": mb, "mr": mr,
+             "rowptr": self.from_numpy(rowptr), "col": self.from_numpy(col),
+             "val": self.from_numpy(val)}
+        if m["nnz"] == 0:   # keep data_ptr() valid
+            m["col"] = torch.zeros(4, dtype=torch.int32, device=self.device)
+            m["val"] = torch.zeros(2, dtype=torch.float64, device=self.device)
+        return m
+
+    def _chk(self, st):
+        if st != 0:
+            raise self.amg.AmgHipError(st, self.lib.amg_hip_last_error().decode())
+
+    def residual(self, m, u_ext, f, r):
+        self._chk(self.lib.amg_hip_dev_residual(m["n"], m["nnz"], m["mb"], m["mr"],
+                  m["rowptr"].data_ptr(), m["col"].data_ptr(), m["val"].data_ptr(),
+                  u_ext.data_ptr(), f.data_ptr(), r.data_ptr(), self.stream()))
+
+    def jacobi(self, m, u_ext, b, u_out, omega, diag_shift):
+        self._chk(self.lib.amg_hip_dev_jacobi(m["n"], m["nnz"], m["mb"], m["mr"],
+                  m["rowptr"].data_ptr(), m["col"].data_ptr(), m["val"].data_ptr(),
+                  u_ext.data_ptr(), b.data_ptr(), u_out.data_ptr(), omega, diag_shift,
+                  self.stream()))
+
+    def spmv(self, m, v_ext, out):
+        self._chk(self.lib.amg_hip_dev_spmv(m["n"], m["nnz"], m["mb"], m["mr"],
+                  m["rowptr"].data_ptr(), m["col"].data_ptr(), m["val"].data_ptr(),
+                  v_ext.data_ptr(), out.data_ptr(), self.stream()))
+
+    def add_(self, y, x):
+        self._chk(self.lib.amg_hip_dev_axpy1(y.numel(), x.data_ptr(), y.data_ptr(), self.stream()))
+
+    def sumsq(self, r):
+        if not hasattr(self, "_scratch"):
+            self._scratch = self.vec(1100)
+        out = self._scratch[1024:1025]
+        self._chk(self.lib.amg_hip_dev_sumsq(r.numel(), r.data_ptr(), out.data_ptr(),
+                                             self._scratch.data_ptr(), self.stream()))
+        return out.clone()
+
+    def sync(self):
+        torch.cuda.current_stream().synchronize()
+
+    def tail(self, colptr, rowind, val, n_levels, omega, sweeps):
+        """The agglomerated coarse part: an ordinary single-GPU solver."""
+        return _HipTail(self, colptr, rowind, val, n_levels, omega, sweeps)
+
+
+class _HipTail:
+    def __init__(self, be, colptr, rowind, val, n_levels, omega, sweeps):
+        amg = be.amg
+        n = colptr.size - 1
+        self.be = be
+        self.mg = amg.Multigrid(colptr, rowind, val, np.zeros(n), n_levels,
+                                smoother=amg.SM_JACOBI, smoother_iters=sweeps, omega=omega,
+                                device=be.device.index)
+        self.n = n
+
+    def cycle(self, f_full, u_full, zero_guess=True):
+        """u_full = one V-cycle on the sub-hierarchy, rhs f_full; from a zero guess
+        (multigrid.hpp:278) unless this is the whole hierarchy."""
+        self.be.sync()                              # f_full was produced on torch's stream
+        self.mg.copy_vec_dev(0, "f", f_full.data_ptr(), True)
+        if zero_guess:
+            self.mg.zero_vec(0, "u")
+        self.mg.vcycle(1)
+        self.mg.copy_vec_dev(0, "u", u_full.data_ptr(), False)
+        self.mg.sync()                              # u_full is consumed on torch's stream
+
+    def rss(self):
+        return self.mg.rss()
+
+
+# ------------------------------------------------------------------- driver ----
+class DistLevel:
+    pass
+
+
+class DistributedVcycle:
+    """multigrid.hpp:263-305 over row-block shards (true Jacobi smoother)."""
+
+    def __init__(self, hierarchy, b, backend, rank, world, omega=0.6, sweeps=2,
+                 agglomerate_rows=131072, group=None, host_staged=False):
+        """hierarchy: object with n_levels, get_n_dofs(l), get_coefficient_matrix(l)
+        -> CSC (colptr, rowind, val) of the (symmetric) level matrix.
+        host_staged: exchange through host buffers (a process group whose backend
+        cannot move device tensors, e.g. gloo with a GPU compute backend)."""
+        self.be, self.rank, self.world, self.group = backend, rank, world, group
+        self.host_staged = bool(host_staged)
+        self.omega, self.sweeps = float(omega), int(sweeps)
+        L = hierarchy.n_levels
+        self.n_levels = L
+        sizes = [hierarchy.get_n_dofs(l) for l in range(L)]
+        # ---- which levels stay distributed ----
+        bounds = [row_bounds(sizes[0], world)]
+        for l in range(1, L):
+            bounds.append(coarse_bounds(bounds[-1], sizes[l]))
+        self.n_dist = 0
+        mats = []
+        for l in range(L):
+            if world == 1:
+                break
+            cp, ri, v = hierarchy.get_coefficient_matrix(l)
+            owned = [bounds[l][g + 1] - bounds[l][g] for g in range(world)]
+            # half bandwidth of the level (every rank derives the same number)
+            rows_of = np.repeat(np.arange(sizes[l], dtype=np.int64), np.diff(cp))
+            hb = int(np.abs(ri.astype(np.int64) - rows_of).max()) if ri.size else 0
+            del rows_of
+            small = min(owned) < max(agglomerate_rows, 1) or min(owned) < hb + 2
+            last_possible = (l == L - 1)   # the coarsest level is always solved redundantly
+            if small or last_possible:
+                break
+            mats.append((cp, ri, v))
+            self.n_dist = l + 1
+        self.bounds = bounds
+        self.sizes = sizes
+        # ---- distributed levels ----
+        self.lv = []
+        for l in range(self.n_dist):
+            cp, ri, v = mats[l]
+            s, e = bounds[l][rank], bounds[l][rank + 1]
+            D = DistLevel()
+            D.n, D.s, D.e = sizes[l], s, e
+            D.A = LocalMatrix(cp, ri, v, s, e)     # symmetric: CSC arrays == CSR arrays
+            D.mat = backend.matrix(D.A.rowptr, D.A.col, D.A.val)
+            n_ext = D.A.halo_lo + (e - s) + D.A.halo_hi
+            D.u = backend.vec(n_ext)
+            D.u2 = backend.vec(n_ext)
+            D.f = backend.vec(e - s)
+            D.r = backend.vec(e - s + 2)            # residual with a width-1 halo each side
+            D.tmp = backend.vec(e - s)
+            cs, ce = bounds[l + 1][rank], bounds[l + 1][rank + 1]
+            D.cs, D.ce = cs, ce
+            rp, c, vv = linear_R_rows(cs, ce, sizes[l], s)
+            D.R = backend.matrix(rp, c, vv)
+            rp, c, vv = linear_P_rows(s, e, sizes[l + 1], cs)
+            D.P = backend.matrix(rp, c, vv)
+            D.uH = backend.vec(ce - cs + 2)         # coarse correction with width-1 halos
+            self.lv.append(D)
+        # halo widths of every rank, so senders know how much a neighbour wants
+        if self.n_dist:
+            mine = torch.tensor([[D.A.halo_lo, D.A.halo_hi] for D in self.lv], dtype=torch.int64,
+                                device="cpu" if self.host_staged else backend.device)
+            allw = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allw, mine, group=group)
+            allw = [t.cpu() for t in allw]
+            self.halo = [[(int(allw[g][l, 0]), int(allw[g][l, 1])) for g in range(world)]
+                         for l in range(self.n_dist)]
+        # ---- the redundant (agglomerated) part: levels n_dist .. L-1 ----
+        la = self.n_dist
+        cp, ri, v = hierarchy.get_coefficient_matrix(la) if la < L else (None, None, None)
+        self.tail = backend.tail(cp, ri, v, L - la, self.omega, self.sweeps)
+        self.tail_n = sizes[la]
+        self.tail_f = backend.vec(self.tail_n)
+        self.tail_u = backend.vec(self.tail_n)
+        if la > 0:
+            counts = [bounds[la][g + 1] - bounds[la][g] for g in range(world)]
+            self.tail_counts = counts
+            self.tail_max = max(counts)
+            self.gather_in = backend.vec(self.tail_max)
+            self.gather_out = backend.vec(self.tail_max * world)
+        # rhs
+        if self.n_dist:
+            D0 = self.lv[0]
+            D0.f.copy_(backend.from_numpy(np.asarray(b[D0.s:D0.e], dtype=np.float64)))
+        else:  # nothing is big enough to shard: every rank runs the whole cycle
+            self.tail_f.copy_(backend.from_numpy(np.asarray(b, dtype=np.float64)))
+
+    # ---- halo exchange of an extended vector [lo | owned | hi] ----
+    def _exchange(self, vec, n_owned, lo, hi, send_prev, send_next):
+        ops = []
+        r, w = self.rank, self.world
+        if r > 0:
+            if lo > 0:
+                ops.append(dist.P2POp(dist.irecv, vec[0:lo], r - 1, self.group))
+            if send_prev > 0:
+                ops.append(dist.P2POp(dist.isend, vec[lo:lo + send_prev], r - 1, self.group))
+        if r < w - 1:
+            if hi > 0:
+                ops.append(dist.P2POp(dist.irecv, vec[lo + n_owned:lo + n_owned + hi], r + 1, self.group))
+            if send_next > 0:
+                ops.append(dist.P2POp(dist.isend, vec[lo + n_owned - send_next:lo + n_owned], r + 1, self.group))
+        if not ops:
+            return
+        if self.host_staged:
+            self.be.sync()
+            staged, back = [], []
+            for op in ops:
+                h = op.tensor.cpu() if op.op is dist.isend else torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
+                staged.append(dist.P2POp(op.op, h, op.peer, self.group))
+                if op.op is dist.irecv:
+                    back.append((op.tensor, h))
+            for req in dist.batch_isend_irecv(staged):
+                req.wait()
+            for dst, h in back:
+                dst.copy_(h)
+            return
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+    def _all_gather(self, out, inp):
+        if self.host_staged:
+            ho = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(ho, inp.cpu(), group=self.group)
+            out.copy_(ho)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def _all_reduce_sum(self, t):
+        if self.host_staged:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            return h
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def _exchange_u(self, l, vec):
+        D = self.lv[l]
+        h = self.halo[l]
+        r = self.rank
+        send_prev = h[r - 1][1] if r > 0 else 0               # what rank-1 wants above its block
+        send_next = h[r + 1][0] if r < self.world - 1 else 0  # what rank+1 wants below its block
+        self._exchange(vec, D.e - D.s, D.A.halo_lo, D.A.halo_hi, send_prev, send_next)
+
+    def _exchange_1(self, vec, n_owned):
+        self._exchange(vec, n_owned, 1, 1, 1, 1)
+
+    # ---- smoother: `sweeps` two-buffer Jacobi passes on level l ----
+    def _smooth(self, l):
+        D = self.lv[l]
+        lo, n = D.A.halo_lo, D.e - D.s
+        for _ in range(self.sweeps):
+            self._exchange_u(l, D.u)
+            self.be.jacobi(D.mat, D.u, D.f, D.u2[lo:lo + n], self.omega, D.A.diag_shift)
+            D.u, D.u2 = D.u2, D.u
+
+    def vcycle(self):
+        be = self.be
+        nd = self.n_dist
+        for l in range(nd):                                   # multigrid.hpp:265
+            D = self.lv[l]
+            lo, n = D.A.halo_lo, D.e - D.s
+            self._smooth(l)                                   # :268
+            self._exchange_u(l, D.u)
+            be.residual(D.mat, D.u, D.f, D.r[1:1 + n])       # :272-274
+            self._exchange_1(D.r, n)
+            nH = D.ce - D.cs
+            if l + 1 < nd:                                    # :278, :281-282
+                C = self.lv[l + 1]
+                C.u.zero_()
+                be.spmv(D.R, D.r, C.f)
+            else:
+                be.spmv(D.R, D.r, self.gather_in[:nH])
+        # ---- agglomerated levels (coarse solve included), redundantly on every rank ----
+        if nd == 0:
+            self.tail.cycle(self.tail_f, self.tail_u, zero_guess=False)
+            return
+        else:
+            self._all_gather(self.gather_out, self.gather_in)
+            off = 0
+            for g, c in enumerate(self.tail_counts):
+                self.tail_f[off:off + c].copy_(self.gather_out[g * self.tail_max:g * self.tail_max + c])
+                off += c
+            self.tail.cycle(self.tail_f, self.tail_u)
+        for l in range(nd - 1, -1, -1):                       # :291
+            D = self.lv[l]
+            lo, n = D.A.halo_lo, D.e - D.s
+            nH = D.ce - D.cs
+            if l + 1 < nd:
+                C = self.lv[l + 1]
+                clo = C.A.halo_lo
+                D.uH[1:1 + nH].copy_(C.u[clo:clo + nH])
+                self._exchange_1(D.uH, nH)
+            else:  # every rank holds the whole level: halo entries are local reads
+                g0 = max(D.cs - 1, 0)
+                g1 = min(D.ce + 1, self.tail_n)
+                D.uH[(g0 - (D.cs - 1)):(g1 - (D.cs - 1))].copy_(self.tail_u[g0:g1])
+            be.spmv(D.P, D.uH, D.tmp)                         # :294-296
+            be.add_(D.u[lo:lo + n], D.tmp)
+            self._smooth(l)                                   # :300
+
+    # ---- diagnostics ----
+    def rss(self):
+        """AMG::rss(A_0, u_0, b) (common.hpp:17-27), all_reduce over ranks."""
+        if self.n_dist == 0:
+            return self.tail.rss()
+        D = self.lv[0]
+        n = D.e - D.s
+        self._exchange_u(0, D.u)
+        self.be.residual(D.mat, D.u, D.f, D.r[1:1 + n])
+        part = self._all_reduce_sum(self.be.sumsq(D.r[1:1 + n]).to(torch.float64))
+        return float(part.item())
+
+    def gather_solution(self):
+        """Level-0 solution on every rank (tests only)."""
+        if self.n_dist == 0:
+            return self.be.to_numpy(self.tail_u).copy()
+        D = self.lv[0]
+        lo, n = D.A.halo_lo, D.e - D.s
+        counts = [self.bounds[0][g + 1] - self.bounds[0][g] for g in range(self.world)]
+        mx = max(counts)
+        buf = self.be.vec(mx)
+        buf[:n].copy_(D.u[lo:lo + n])
+        out = self.be.vec(mx * self.world)
+        self._all_gather(out, buf)
+        out = self.be.to_numpy(out)
+        return np.concatenate([out[g * mx:g * mx + c] for g, c in enumerate(counts)])
+
+
+# --------------------------------------------------------------------- bench ---
+def bench(args):
+    """bench.py --gpus N (N > 1): launched by torch.distributed.run, one rank per GPU."""
+    import amg_ctypes as amg
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world,
+                            device_id=torch.device("cuda", local))
+    be = HipBackend(local)
+    from bench import n_levels_for, HBM_PEAK_GBS
+    t0 = time.time()
+    colptr, rowind, val = amg.laplacian(args.n)
+    b = amg.rhs(args.n)
+    L = args.levels or n_levels_for(args.n)
+    hier = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_JACOBI,
+                         smoother_iters=args.sweeps, omega=args.omega, host_only=True)
+    del colptr, rowind, val
+    dv = DistributedVcycle(hier, b, be, rank, world, omega=args.omega, sweeps=args.sweeps,
+                           agglomerate_rows=args.agglomerate_rows)
+    hier.close()
+    setup_s = time.time() - t0
+    for _ in range(args.warmup):
+        dv.vcycle()
+    rss0 = dv.rss()
+    be.sync()
+    dist.barrier()
+    be.sync()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        dv.vcycle()
+    be.sync()
+    dist.barrier()
+    be.sync()
+    dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=be.device)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    rss = dv.rss()
+    # dominant kernel: this rank's level-0 Jacobi sweep (HIP events on torch's stream)
+    D = dv.lv[0]
+    lo, n = D.A.halo_lo, D.e - D.s
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.profile_launches)]
+    for a, c in ev:
+        a.record()
+        be.jacobi(D.mat, D.u, D.f, D.u2[lo:lo + n], dv.omega, D.A.diag_shift)
+        c.record()
+    be.sync()
+    ms = [a.elapsed_time(c) for a, c in ev]
+    avg_ms = sum(ms) / len(ms)
+    sweep_bytes = 12.0 * D.A.nnz + 28.0 * n
+    out = None
+    if rank == 0:
+        if args.warmup >= 1 and not (rss < rss0):
+            raise SystemExit(f"V-cycle iteration is not converging (rss {rss0:.3e} -> {rss:.3e})")
+        achieved = sweep_bytes / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "V-cycles/sec, 2D Poisson N=4096^2 (fine-grid smoother HBM GB/s under roofline)",
+            "value": args.steps / dt, "unit": "V-cycles/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": (f"2D 5-point Poisson {args.n}x{args.n} (Grid::laplacian/rhs), true Jacobi "
+                             f"omega={args.omega} {args.sweeps}+{args.sweeps} sweeps, {L}-level V-cycle, "
+                             f"row-block shards over {world} GPUs ({dv.n_dist} distributed levels, "
+                             f"rest agglomerated), fp64"),
+                "n": args.n, "levels": L, "distributed_levels": dv.n_dist,
+                "agglomerate_rows": args.agglomerate_rows, "setup_seconds": setup_s,
+                "rss_after_warmup": rss0, "rss_after_steps": rss,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "csr_stage_kernel<CSR_JACOBI,6,5> (rank 0 level-0 Jacobi sweep)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_ms,
+                "launches_timed": len(ms),
+            },
+        }
+    dist.barrier()
+    dist.destroy_process_group()
+    return out

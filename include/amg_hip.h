@@ -73,7 +73,11 @@ typedef struct {
                               LinearInterpolator, use the matrix-free stride-2
                               kernels (bit-identical to the CSR path)           */
   int32_t layout;          /* amg_hip_layout of the level matrices on the device  */
-  int32_t reserved[7];
+  int32_t host_only;       /* 1: build the hierarchy on the host only (no device is
+                              touched); getters work, compute entry points fail.
+                              Used by the row-block multi-GPU driver, where every
+                              rank slices its own rows out of the hierarchy.       */
+  int32_t reserved[6];
 } amg_hip_options;
 
 typedef struct amg_hip_solver amg_hip_solver; /* opaque; owns device memory    */
@@ -159,6 +163,17 @@ amg_hip_status amg_hip_get_vec(amg_hip_solver* s, int32_t level, int32_t which,
                                double* out);
 amg_hip_status amg_hip_set_vec(amg_hip_solver* s, int32_t level, int32_t which,
                                const double* in);
+/* Device-side copy between a level vector of the solver and caller-owned
+ * DEVICE memory (n_dofs(level) doubles), enqueued on the solver's stream:
+ * to_solver = 1 copies src -> solver vector, 0 copies solver vector -> dst.
+ * which as in amg_hip_get_vec.  Lets a host that owns device buffers (the
+ * multi-GPU driver's agglomerated coarse part) feed a right-hand side and take
+ * the solution without a host round trip.                                      */
+amg_hip_status amg_hip_copy_vec_dev(amg_hip_solver* s, int32_t level, int32_t which,
+                                    void* dev_ptr, int32_t to_solver);
+/* Zero-fill a level vector on the solver's stream. */
+amg_hip_status amg_hip_zero_vec(amg_hip_solver* s, int32_t level, int32_t which);
+
 /* Half-bandwidth of the factored coarsest operator. */
 int64_t amg_hip_coarse_halfbw(const amg_hip_solver* s);
 /* Multicolour smoother: colour of every dof of `level` (n_dofs int32) and the
