@@ -92,6 +92,15 @@ def run_single(args):
         raise SystemExit(f"V-cycle iteration is not converging (rss {rss0:.3e} -> {rss:.3e})")
     sizes = [mg.get_n_dofs(l) for l in range(L)]
     achieved = sweep_bytes / (avg_ms * 1e-3) / 1e9
+    # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run
+    # inside this process); only quoted for the configuration it was measured on.
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc) and args.n == 4096:
+        rec = json.load(open(pmc))
+        k = rec["kernels"].get("sell_kernel<1, 5>@16777216")
+        if k and rec.get("n") == args.n:
+            traffic, traffic_src = k["traffic_bytes"], "profiles/r01_pmc_traffic.md: " + rec["source"]
     out = {
         "metric": "V-cycles/sec, 2D Poisson N=4096^2 (fine-grid smoother HBM GB/s under roofline)",
         "value": args.steps / dt,
@@ -121,7 +130,8 @@ def run_single(args):
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": sweep_bytes,
             "avg_launch_ms": avg_ms,
             "min_launch_ms": min_ms,

@@ -58,6 +58,18 @@ __global__ __launch_bounds__(256) void read_f4(const float4* __restrict__ a, flo
   b[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// FETCH_SIZE calibration: the same 1 GiB read with 8-byte and 4-byte lane loads
+__global__ __launch_bounds__(256) void read_f2(const double* __restrict__ a, double* __restrict__ b, int64_t n) {
+  double s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += a[i];
+  b[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void read_f1(const float* __restrict__ a, float* __restrict__ b, int64_t n) {
+  float s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += a[i];
+  b[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // --------------------------------------------------- V0: block-staged (product) --
 template <int K, int U>
 __global__ __launch_bounds__(256) void jac_v0(int64_t n, int64_t nnz, const int32_t* __restrict__ rowptr,
@@ -261,8 +273,8 @@ int main(int argc, char** argv) {
   const int64_t n4 = (int64_t)64 << 20; float4 *ca, *cb; CHECK(hipMalloc(&ca, n4 * 16)); CHECK(hipMalloc(&cb, n4 * 16));
   CHECK(hipMemset(ca, 1, n4 * 16));
 
-  enum { COPY, READ, V0, V0b, V1a, V1b, V1c, V2, V3a, V3b, NV };
-  const char* names[NV] = {"copy_f4 (1GiB->1GiB, bytes=2GiB)", "read_f4 (1GiB read)", "v0 block-staged K6 U8 (product)", "v0 block-staged K6 U5",
+  enum { COPY, READ, READ8, READ4, V0, V0b, V1a, V1b, V1c, V2, V3a, V3b, NV };
+  const char* names[NV] = {"copy_f4 (1GiB->1GiB, bytes=2GiB)", "read_f4 (1GiB read)", "read 8B/lane (1GiB read)", "read 4B/lane (1GiB read)", "v0 block-staged K6 U8 (product)", "v0 block-staged K6 U5",
                            "v1 wave-private K6 U8 W4", "v1 wave-private K6 U5 W4", "v1 wave-private K6 U5 W8", "v2 direct CSR U5", "v3 SELL-64 U5", "v3 SELL-64 U8"};
   std::vector<std::vector<float>> t(NV);
   Timer tm;
@@ -270,6 +282,8 @@ int main(int argc, char** argv) {
     switch (v) {
       case COPY: copy_f4<<<2048, 256>>>(ca, cb, n4); break;
       case READ: read_f4<<<2048, 256>>>(ca, cb, n4); break;
+      case READ8: read_f2<<<2048, 256>>>((const double*)ca, (double*)cb, n4 * 2); break;
+      case READ4: read_f1<<<2048, 256>>>((const float*)ca, (float*)cb, n4 * 4); break;
       case V0: jac_v0<6, 8><<<grid256, 256, (256 * 6 + 4) * 12>>>(N, nnz, rowptr, col, val, x, f, out, omega); break;
       case V0b: jac_v0<6, 5><<<grid256, 256, (256 * 6 + 4) * 12>>>(N, nnz, rowptr, col, val, x, f, out, omega); break;
       case V1a: jac_v1<6, 8, 4><<<grid256, 256>>>((int)N, (int)nnz, rowptr, col, val, x, f, out, omega); break;
@@ -299,7 +313,7 @@ int main(int argc, char** argv) {
   for (int v = 0; v < NV; ++v) {
     std::sort(t[v].begin(), t[v].end());
     const float med = t[v][t[v].size() / 2], mn = t[v][0];
-    const double b = v == COPY ? 2.0 * n4 * 16 : (v == READ ? 1.0 * n4 * 16 : bytes);
+    const double b = v == COPY ? 2.0 * n4 * 16 : ((v == READ || v == READ8 || v == READ4) ? 1.0 * n4 * 16 : bytes);
     printf("%-38s median %8.1f us  min %8.1f us   %7.0f GB/s (median)  %5.1f%% of 8 TB/s\n", names[v], med * 1e3, mn * 1e3, b / med / 1e6, b / med / 1e6 / 80.0);
   }
   return 0;
