@@ -398,6 +398,37 @@ void greedy_coloring(const Sparse& M, std::vector<int32_t>* color,
   *n_colors = nc;
 }
 
+void build_color_perm(const Sparse& M, const std::vector<int32_t>& color, int32_t n_colors,
+                      ColorPerm* P) {
+  const int64_t n = M.n_outer;
+  std::vector<int64_t> cnt(n_colors, 0);
+  for (int64_t i = 0; i < n; ++i) cnt[color[i]]++;
+  P->start.assign(n_colors + 1, 0);
+  for (int32_t c = 0; c < n_colors; ++c) P->start[c + 1] = P->start[c] + (cnt[c] + 63) / 64 * 64;
+  const int64_t ns = P->start[n_colors];
+  P->rowid.assign(ns, -1);
+  std::vector<int64_t> cur(P->start.begin(), P->start.end() - 1);
+  for (int64_t i = 0; i < n; ++i) P->rowid[cur[color[i]]++] = (int32_t)i;  // ascending inside a colour
+  Sparse& R = P->rows;
+  R.n_outer = ns;
+  R.n_inner = M.n_inner;
+  R.ptr.assign(ns + 1, 0);
+  R.idx.clear();
+  R.val.clear();
+  R.idx.reserve(M.idx.size());
+  R.val.reserve(M.val.size());
+  for (int64_t p = 0; p < ns; ++p) {
+    const int32_t i = P->rowid[p];
+    if (i >= 0)
+      for (int32_t q = M.ptr[i]; q < M.ptr[i + 1]; ++q)
+        if (M.val[q] != 0.0 || M.idx[q] == i) {
+          R.idx.push_back(M.idx[q]);
+          R.val.push_back(M.val[q]);
+        }
+    R.ptr[p + 1] = (int32_t)R.idx.size();
+  }
+}
+
 // ---------------------------------------------------------------- grid.hpp ---
 Sparse laplacian(int dim, int64_t n) {
   // grid.hpp:31,50-75,88-98.  D = tridiag(1,-2,1)/(h*h) with h = 2/(n+1);

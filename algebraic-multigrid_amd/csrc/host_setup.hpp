@@ -116,6 +116,18 @@ std::string build_lex_schedule(const Sparse& rows_as, bool backward,
 void greedy_coloring(const Sparse& rows_as, std::vector<int32_t>* color,
                      int32_t* n_colors);
 
+// Colour-permuted copy for the multicolour kernel: the rows of colour c are
+// stored contiguously from storage row start[c] (a multiple of 64, padded with
+// empty rows); rowid[p] = dof of storage row p or -1.  Exact-zero entries are
+// dropped (they change nothing: x + 0*u == x for finite u).
+struct ColorPerm {
+  Sparse rows;                  // n_outer = storage rows, columns = natural dof indices
+  std::vector<int32_t> rowid;   // storage rows
+  std::vector<int64_t> start;   // n_colors + 1
+};
+void build_color_perm(const Sparse& rows_as, const std::vector<int32_t>& color,
+                      int32_t n_colors, ColorPerm* out);
+
 // ---- Grid<double> (grid.hpp) ------------------------------------------------
 Sparse laplacian(int dim, int64_t n);       // CSC (== CSR, symmetric)
 void rhs(int dim, int64_t n, double* b);

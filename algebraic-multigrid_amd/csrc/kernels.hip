@@ -203,22 +203,31 @@ hipError_t launch_csr(int mode, int64_t n, int64_t nnz, int max_block_nnz,
 // Measured on the 4096^2 fine level: 6.2 TB/s algorithmic vs 5.6 TB/s for K-CSR
 // (tools/kbench.hip) -- the panel layout is what "CSR laid out for coalesced
 // HBM reads" comes to on wave64 hardware.
+// MODE CSR_GS (multicolour Gauss-Seidel): rows are the colour-permuted rows
+// [row0, row0 + count) of the matrix, rowid[p] is the dof each one updates
+// (-1 = padding), x is updated IN PLACE -- rows of one colour do not reference
+// each other, so the launch is race-free.
 template <int MODE, int U>
 __global__ __launch_bounds__(256) void sell_kernel(
     int n, const int64_t* __restrict__ soff, const int32_t* __restrict__ scol,
-    const double* __restrict__ sval, const double* __restrict__ x,
-    const double* __restrict__ f, double* __restrict__ out, double omega) {
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  const int s = row >> 6;
+    const double* __restrict__ sval, const double* x, const double* __restrict__ f,
+    double* out, double omega, const int32_t* __restrict__ rowid, int row0) {
+  const int p = row0 + blockIdx.x * 256 + threadIdx.x;  // storage row
+  const int s = p >> 6;
   if ((s << 6) >= n) return;  // whole wave past the end
   const int64_t o0 = soff[s], o1 = soff[s + 1];
   const int w = (int)((o1 - o0) >> 6);  // wave-uniform panel width
-  const int64_t base = o0 + (row & 63);
-  const bool live = row < n;
+  const int64_t base = o0 + (p & 63);
+  int row = p;
+  bool live = p < n;
+  if (MODE == CSR_GS) {
+    row = live ? rowid[p] : -1;
+    live = row >= 0;
+  }
   double fi = 0.0, xi = 0.0;
   if (live) {
     if (MODE != CSR_SPMV) fi = f[row];
-    if (MODE == CSR_JACOBI) xi = x[row];
+    if (MODE == CSR_JACOBI || MODE == CSR_GS) xi = x[row];
   }
   double acc = (MODE == CSR_RESID) ? fi : 0.0;
   double diag = 0.0;
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(256) void sell_kernel(
       if (j0 + u < w && c[u] >= 0) {
         if (MODE == CSR_RESID) {
           acc -= v[u] * xx[u];
-        } else if (MODE == CSR_JACOBI) {
+        } else if (MODE == CSR_JACOBI || MODE == CSR_GS) {
           if (c[u] == row) diag = v[u];
           else acc += v[u] * xx[u];
         } else {
@@ -252,6 +261,8 @@ __global__ __launch_bounds__(256) void sell_kernel(
       out[row] = acc;
     } else if (MODE == CSR_JACOBI) {
       out[row] = (diag == 0.0) ? xi : xi + omega * ((fi - acc) / diag - xi);
+    } else if (MODE == CSR_GS) {
+      if (diag != 0.0) out[row] = (fi - acc) / diag;  // smoother.hpp:136
     } else {
       const double d = fi - acc;
       out[row] = d * d;
@@ -262,21 +273,26 @@ __global__ __launch_bounds__(256) void sell_kernel(
 template <int MODE, int U>
 static hipError_t launch_sell_u(int64_t n, const int64_t* soff, const int32_t* scol,
                                 const double* sval, const double* x, const double* f,
-                                double* out, double omega, hipStream_t st) {
-  const unsigned grid = (unsigned)((n + 255) / 256);
+                                double* out, double omega, const int32_t* rowid, int64_t row0,
+                                int64_t count, hipStream_t st) {
+  const unsigned grid = (unsigned)((count + 255) / 256);
   hipLaunchKernelGGL((sell_kernel<MODE, U>), dim3(grid), dim3(256), 0, st, (int)n, soff, scol,
-                     sval, x, f, out, omega);
+                     sval, x, f, out, omega, rowid, (int)row0);
   return hipGetLastError();
 }
 template <int MODE>
 static hipError_t launch_sell_mode(int64_t n, int max_width, const int64_t* soff,
                                    const int32_t* scol, const double* sval, const double* x,
-                                   const double* f, double* out, double omega, hipStream_t st) {
-  if (max_width <= 3) return launch_sell_u<MODE, 3>(n, soff, scol, sval, x, f, out, omega, st);
-  if (max_width <= 5) return launch_sell_u<MODE, 5>(n, soff, scol, sval, x, f, out, omega, st);
-  if (max_width <= 7) return launch_sell_u<MODE, 7>(n, soff, scol, sval, x, f, out, omega, st);
-  if (max_width <= 9) return launch_sell_u<MODE, 9>(n, soff, scol, sval, x, f, out, omega, st);
-  return launch_sell_u<MODE, 8>(n, soff, scol, sval, x, f, out, omega, st);
+                                   const double* f, double* out, double omega,
+                                   const int32_t* rowid, int64_t row0, int64_t count,
+                                   hipStream_t st) {
+#define AMG_SELL_U(UU) launch_sell_u<MODE, UU>(n, soff, scol, sval, x, f, out, omega, rowid, row0, count, st)
+  if (max_width <= 3) return AMG_SELL_U(3);
+  if (max_width <= 5) return AMG_SELL_U(5);
+  if (max_width <= 7) return AMG_SELL_U(7);
+  if (max_width <= 9) return AMG_SELL_U(9);
+  return AMG_SELL_U(8);
+#undef AMG_SELL_U
 }
 hipError_t launch_sell(int mode, int64_t n, int max_width, const int64_t* soff,
                        const int32_t* scol, const double* sval, const double* x,
@@ -284,12 +300,22 @@ hipError_t launch_sell(int mode, int64_t n, int max_width, const int64_t* soff,
   if (n <= 0) return hipSuccess;
   if (n >= ((int64_t)1 << 31) - 256) return hipErrorInvalidValue;
   switch (mode) {
-    case CSR_RESID: return launch_sell_mode<CSR_RESID>(n, max_width, soff, scol, sval, x, f, out, omega, st);
-    case CSR_JACOBI: return launch_sell_mode<CSR_JACOBI>(n, max_width, soff, scol, sval, x, f, out, omega, st);
-    case CSR_SPMV: return launch_sell_mode<CSR_SPMV>(n, max_width, soff, scol, sval, x, f, out, omega, st);
-    case CSR_RSSQ: return launch_sell_mode<CSR_RSSQ>(n, max_width, soff, scol, sval, x, f, out, omega, st);
+    case CSR_RESID: return launch_sell_mode<CSR_RESID>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, st);
+    case CSR_JACOBI: return launch_sell_mode<CSR_JACOBI>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, st);
+    case CSR_SPMV: return launch_sell_mode<CSR_SPMV>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, st);
+    case CSR_RSSQ: return launch_sell_mode<CSR_RSSQ>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, st);
   }
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_sell_gs_color(int64_t n_storage, int max_width, const int64_t* soff,
+                                const int32_t* scol, const double* sval, const int32_t* rowid,
+                                int64_t row0, int64_t count, const double* f, double* u,
+                                hipStream_t st) {
+  if (count <= 0) return hipSuccess;
+  if (n_storage >= ((int64_t)1 << 31) - 256 || (row0 & 63)) return hipErrorInvalidValue;
+  return launch_sell_mode<CSR_GS>(n_storage, max_width, soff, scol, sval, u, f, u, 1.0, rowid,
+                                  row0, count, st);
 }
 
 // Device-side scan of the row pointer for the two launch parameters above

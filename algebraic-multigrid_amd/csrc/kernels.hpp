@@ -9,7 +9,8 @@ enum CsrMode {
   CSR_RESID = 0,   // out = f - A x   (ascending column order per row)
   CSR_JACOBI = 1,  // out = x_i + omega*((f_i - sum_{j!=i} a_ij x_j)/a_ii - x_i)
   CSR_SPMV = 2,    // out = A x
-  CSR_RSSQ = 3     // out_i = (f_i - (A x)_i)^2
+  CSR_RSSQ = 3,    // out_i = (f_i - (A x)_i)^2
+  CSR_GS = 4       // in-place Gauss-Seidel update of one colour (K-SELL only)
 };
 
 // max_block_nnz: max entries in any 256-row block; max_row_nnz: longest row.
@@ -22,6 +23,13 @@ hipError_t launch_csr(int mode, int64_t n, int64_t nnz, int max_block_nnz,
 hipError_t launch_sell(int mode, int64_t n, int max_width, const int64_t* soff,
                        const int32_t* scol, const double* sval, const double* x,
                        const double* f, double* out, double omega, hipStream_t st);
+// One colour of the multicolour Gauss-Seidel: storage rows [row0, row0+count) of a
+// colour-permuted SELL-64 matrix (row0 % 64 == 0), rowid = dof of each storage
+// row (-1 pads); u[rowid] = (f - sum_{j != i} a_ij u_j) / a_ii in place.
+hipError_t launch_sell_gs_color(int64_t n_storage, int max_width, const int64_t* soff,
+                                const int32_t* scol, const double* sval, const int32_t* rowid,
+                                int64_t row0, int64_t count, const double* f, double* u,
+                                hipStream_t st);
 // out2[0] = max_block_nnz, out2[1] = max_row_nnz (device int32[2])
 hipError_t launch_csr_shape(int64_t n, const int32_t* rowptr, int32_t* out2,
                             hipStream_t st);

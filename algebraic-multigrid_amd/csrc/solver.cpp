@@ -181,11 +181,6 @@ hipError_t upload_lex(const LexSchedule& S, LexOnDev* L) {
   return hipSuccess;
 }
 
-struct ColorSet {  // rows of one colour, for the multicolour smoother
-  int64_t count = 0;
-  DevMem rows;  // int32 row ids ascending
-};
-
 struct Level {
   int64_t n = 0;
   Sparse A_csc;            // host copy, what get_coefficient_matrix returns
@@ -200,10 +195,12 @@ struct Level {
   DevCsr P_rows, R_rows;   // CSR(P), CSR(R)
   // exact lexicographic schedules
   std::unique_ptr<LexOnDev> lex_fwd, lex_bwd;
-  // multicolour
+  // multicolour: colour-permuted SELL-64 copy + dof of every storage row
   std::vector<int32_t> color;
   int32_t n_colors = 0;
-  std::vector<ColorSet> color_sets;
+  DevMat mc_mat;
+  DevMem mc_rowid;
+  std::vector<int64_t> mc_start;
 };
 
 }  // namespace
@@ -277,8 +274,18 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l) {
   return fail(AMG_HIP_EINVAL, "unknown smoother kind");
 }
 
-amg_hip_status enqueue_multicolor(amg_hip_solver*, Level&, hipStream_t) {
-  return fail(AMG_HIP_EUNSUPPORTED, "multicolour Gauss-Seidel: not built yet");
+// one symmetric pass: colours 0..nc-1 then nc-1..0
+amg_hip_status enqueue_multicolor(amg_hip_solver*, Level& L, hipStream_t st) {
+  const DevMat& A = L.mc_mat;
+  auto one = [&](int c) -> hipError_t {
+    return launch_sell_gs_color(A.n_rows, A.max_width, A.soff.as<int64_t>(), A.scol.as<int32_t>(),
+                                A.sval.as<double>(), L.mc_rowid.as<int32_t>(), L.mc_start[c],
+                                L.mc_start[c + 1] - L.mc_start[c], L.f.as<double>(),
+                                L.u.as<double>(), st);
+  };
+  for (int c = 0; c < L.n_colors; ++c) HIP_TRY(one(c));
+  for (int c = L.n_colors - 1; c >= 0; --c) HIP_TRY(one(c));
+  return AMG_HIP_OK;
 }
 
 amg_hip_status enqueue_residual(amg_hip_solver* s, int l) {
@@ -465,8 +472,17 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
       HIP_TRY(upload_lex(F, L.lex_fwd.get()));
     } else if (s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS) {
       greedy_coloring(L.A_csc, &L.color, &L.n_colors);
+      ColorPerm CP;
+      build_color_perm(L.A_csc, L.color, L.n_colors, &CP);  // column-as-row walk, like SpGS
+      if (CP.rows.n_outer >= ((int64_t)1 << 31) - 512)
+        return fail(AMG_HIP_EUNSUPPORTED, "multicolour smoother: level too large for int32 rows");
+      HIP_TRY(upload_mat(CP.rows, AMG_HIP_LAYOUT_SELL, &L.mc_mat));
+      HIP_TRY(upload(L.mc_rowid, CP.rowid.data(), CP.rowid.size()));
+      L.mc_start = CP.start;
     }
     }  // dev
+    if (!dev && s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS)
+      greedy_coloring(L.A_csc, &L.color, &L.n_colors);
     if (l + 1 == n_levels) break;
     // ---- transfer operators for level l -> l+1 ----
     const int64_t n_h = L.n;

@@ -73,8 +73,12 @@ def run_single(args):
     colptr, rowind, val = amg.laplacian(args.n)
     b = amg.rhs(args.n)
     L = args.levels or n_levels_for(args.n)
-    mg = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_JACOBI,
-                       smoother_iters=args.sweeps, omega=args.omega, use_graph=not args.no_graph)
+    if args.smoother == "multicolor":   # BASELINE configs[3] smoother; one symmetric colour pass
+        mg = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_MULTICOLOR_GS,
+                           smoother_iters=1, use_graph=not args.no_graph)
+    else:
+        mg = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_JACOBI,
+                           smoother_iters=args.sweeps, omega=args.omega, use_graph=not args.no_graph)
     setup_s = time.time() - t0
     del colptr, rowind, val
     mg.vcycle(args.warmup)
@@ -85,10 +89,13 @@ def run_single(args):
     mg.sync()
     dt = time.perf_counter() - t1
     # dominant kernel: level-0 Jacobi sweep, HIP events on the solver's stream
-    avg_ms, min_ms = mg.profile_fine_sweep(args.profile_launches)
+    if args.smoother == "jacobi":
+        avg_ms, min_ms = mg.profile_fine_sweep(args.profile_launches)
+    else:
+        avg_ms, min_ms = float("nan"), float("nan")
     cyc_bytes, sweep_bytes = mg.cycle_bytes()
     rss = mg.rss()
-    if args.warmup >= 1 and not (rss < rss0):
+    if args.warmup >= 1 and args.smoother == "jacobi" and not (rss < rss0):
         raise SystemExit(f"V-cycle iteration is not converging (rss {rss0:.3e} -> {rss:.3e})")
     sizes = [mg.get_n_dofs(l) for l in range(L)]
     achieved = sweep_bytes / (avg_ms * 1e-3) / 1e9
@@ -118,7 +125,7 @@ def run_single(args):
             "workload": (f"2D 5-point Poisson {args.n}x{args.n} (Grid::laplacian/rhs), true Jacobi "
                          f"smoother omega={args.omega} {args.sweeps}+{args.sweeps} sweeps, "
                          f"{L}-level V-cycle, coarsest {sizes[-1]} dofs, fp64, 1xMI355X"),
-            "n": args.n, "levels": L, "smoother": "jacobi", "omega": args.omega,
+            "n": args.n, "levels": L, "smoother": args.smoother, "omega": args.omega,
             "sweeps": args.sweeps, "graph": not args.no_graph,
             "cycle_algorithmic_bytes": cyc_bytes, "cycle_GBps": cyc_bytes / (dt / args.steps) / 1e9,
             "setup_seconds": setup_s, "rss_after_warmup": rss0, "rss_after_steps": rss,
@@ -155,6 +162,7 @@ def main():
                     help="Jacobi relaxation; must stay below 2/lambda_max(D^-1 A) ~ 0.67 on the "
                          "reference's flat-index Galerkin levels (DESIGN.md)")
     ap.add_argument("--sweeps", type=int, default=2, help="Jacobi sweeps per smooth() call")
+    ap.add_argument("--smoother", choices=["jacobi", "multicolor"], default="jacobi")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=2048, help="grid of the CPU baseline sample")

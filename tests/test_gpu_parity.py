@@ -392,3 +392,47 @@ def test_3d_7point_vcycle(amg, oracle):
         mg.vcycle()
     assert np.array_equal(mg.get_soln(0), ref.get_vec(0, "u"))
     mg.close()
+
+
+def test_multicolor_gs_vcycle_bit_exact(amg, oracle):
+    """Build-side symmetric multicolour Gauss-Seidel (BASELINE config 4 smoother).
+    Colouring comes from the product (greedy, row order); the oracle twin replays
+    the same colours.  Level 0 of the 5-point operator must come out red-black."""
+    n, L = 64, 5
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    mg = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_MULTICOLOR_GS, smoother_iters=1)
+    ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_MULTICOLOR, smoother_iters=1)
+    for l in range(L):
+        color, nc = mg.get_colors(l)
+        ref.set_colors(l, color, nc)
+        # proper colouring of the numerically non-zero pattern
+        S = ref.level_matrix(l).to_scipy().tocoo()
+        m = (S.row != S.col) & (S.data != 0)
+        assert not np.any(color[S.row[m]] == color[S.col[m]]), l
+        assert color.min() == 0 and color.max() == nc - 1
+        if l == 0:
+            i, j = np.divmod(np.arange(n * n), n)
+            assert nc == 2 and np.array_equal(color, (i + j) % 2)     # red-black
+    rss = []
+    for c in range(6):
+        ref.vcycle()
+        mg.vcycle()
+        assert np.array_equal(mg.get_soln(0), ref.get_vec(0, "u")), c
+        rss.append(mg.rss())
+    assert rss[-1] < 1e-2 * rss[0]          # converges (oracle twin: 1.4e3 -> 4.8 in 6 cycles)
+    mg.close()
+
+
+def test_multicolor_gs_two_iterations_3d(amg, oracle):
+    n, L = 12, 3
+    A, b = oracle.laplacian(n, dim=3), oracle.rhs(n, dim=3)
+    mg = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_MULTICOLOR_GS, smoother_iters=2)
+    ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_MULTICOLOR, smoother_iters=2)
+    for l in range(L):
+        color, nc = mg.get_colors(l)
+        ref.set_colors(l, color, nc)
+    for _ in range(3):
+        ref.vcycle()
+        mg.vcycle()
+    assert np.array_equal(mg.get_soln(0), ref.get_vec(0, "u"))
+    mg.close()
