@@ -211,7 +211,26 @@ template <int MODE, int U>
 __global__ __launch_bounds__(256) void sell_kernel(
     int n, const int64_t* __restrict__ soff, const int32_t* __restrict__ scol,
     const double* __restrict__ sval, const double* x, const double* __restrict__ f,
-    double* out, double omega, const int32_t* __restrict__ rowid, int row0) {
+    double* out, double omega, const int32_t* __restrict__ rowid, int row0,
+    const double* __restrict__ uH, int nH) {
+  // CSR_JACOBI_P: x is not the smoother's input yet -- the input is x + P uH
+  // (LinearInterpolator prolongation, interpolator.hpp:106-129), formed on the
+  // fly per gathered entry in the same order as K-ProlongAdd:
+  //   t[2j+1] = 0 + 1.0 uH[j];  t[2j] = (0 + 0.5 uH[j-1]) + 0.5 uH[j].
+  auto corrected = [&](int c) -> double {
+    const double xc = x[c];
+    const int j = c >> 1;
+    const double a = uH[(j >= 1 && j - 1 < nH) ? j - 1 : 0];
+    const double b = uH[j < nH ? j : 0];
+    double t = 0.0;
+    if (c & 1) {
+      if (j < nH) t += 1.0 * b;
+    } else {
+      if (j >= 1 && j - 1 < nH) t += 0.5 * a;
+      if (j < nH) t += 0.5 * b;
+    }
+    return xc + t;
+  };
   const int p = row0 + blockIdx.x * 256 + threadIdx.x;  // storage row
   const int s = p >> 6;
   if ((s << 6) >= n) return;  // whole wave past the end
@@ -228,6 +247,7 @@ __global__ __launch_bounds__(256) void sell_kernel(
   if (live) {
     if (MODE != CSR_SPMV) fi = f[row];
     if (MODE == CSR_JACOBI || MODE == CSR_GS) xi = x[row];
+    if (MODE == CSR_JACOBI_P) xi = corrected(row);
   }
   double acc = (MODE == CSR_RESID) ? fi : 0.0;
   double diag = 0.0;
@@ -241,13 +261,16 @@ __global__ __launch_bounds__(256) void sell_kernel(
       v[u] = sval[base + ((int64_t)j << 6)];
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) xx[u] = x[c[u] >= 0 ? c[u] : 0];
+    for (int u = 0; u < U; ++u) {
+      if (MODE == CSR_JACOBI_P) xx[u] = corrected(c[u] >= 0 ? c[u] : 0);
+      else xx[u] = x[c[u] >= 0 ? c[u] : 0];
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (j0 + u < w && c[u] >= 0) {
         if (MODE == CSR_RESID) {
           acc -= v[u] * xx[u];
-        } else if (MODE == CSR_JACOBI || MODE == CSR_GS) {
+        } else if (MODE == CSR_JACOBI || MODE == CSR_GS || MODE == CSR_JACOBI_P) {
           if (c[u] == row) diag = v[u];
           else acc += v[u] * xx[u];
         } else {
@@ -259,7 +282,7 @@ __global__ __launch_bounds__(256) void sell_kernel(
   if (live) {
     if (MODE == CSR_RESID || MODE == CSR_SPMV) {
       out[row] = acc;
-    } else if (MODE == CSR_JACOBI) {
+    } else if (MODE == CSR_JACOBI || MODE == CSR_JACOBI_P) {
       out[row] = (diag == 0.0) ? xi : xi + omega * ((fi - acc) / diag - xi);
     } else if (MODE == CSR_GS) {
       if (diag != 0.0) out[row] = (fi - acc) / diag;  // smoother.hpp:136
@@ -274,10 +297,10 @@ template <int MODE, int U>
 static hipError_t launch_sell_u(int64_t n, const int64_t* soff, const int32_t* scol,
                                 const double* sval, const double* x, const double* f,
                                 double* out, double omega, const int32_t* rowid, int64_t row0,
-                                int64_t count, hipStream_t st) {
+                                int64_t count, const double* uH, int64_t nH, hipStream_t st) {
   const unsigned grid = (unsigned)((count + 255) / 256);
   hipLaunchKernelGGL((sell_kernel<MODE, U>), dim3(grid), dim3(256), 0, st, (int)n, soff, scol,
-                     sval, x, f, out, omega, rowid, (int)row0);
+                     sval, x, f, out, omega, rowid, (int)row0, uH, (int)nH);
   return hipGetLastError();
 }
 template <int MODE>
@@ -285,8 +308,8 @@ static hipError_t launch_sell_mode(int64_t n, int max_width, const int64_t* soff
                                    const int32_t* scol, const double* sval, const double* x,
                                    const double* f, double* out, double omega,
                                    const int32_t* rowid, int64_t row0, int64_t count,
-                                   hipStream_t st) {
-#define AMG_SELL_U(UU) launch_sell_u<MODE, UU>(n, soff, scol, sval, x, f, out, omega, rowid, row0, count, st)
+                                   const double* uH, int64_t nH, hipStream_t st) {
+#define AMG_SELL_U(UU) launch_sell_u<MODE, UU>(n, soff, scol, sval, x, f, out, omega, rowid, row0, count, uH, nH, st)
   if (max_width <= 3) return AMG_SELL_U(3);
   if (max_width <= 5) return AMG_SELL_U(5);
   if (max_width <= 7) return AMG_SELL_U(7);
@@ -300,12 +323,22 @@ hipError_t launch_sell(int mode, int64_t n, int max_width, const int64_t* soff,
   if (n <= 0) return hipSuccess;
   if (n >= ((int64_t)1 << 31) - 256) return hipErrorInvalidValue;
   switch (mode) {
-    case CSR_RESID: return launch_sell_mode<CSR_RESID>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, st);
-    case CSR_JACOBI: return launch_sell_mode<CSR_JACOBI>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, st);
-    case CSR_SPMV: return launch_sell_mode<CSR_SPMV>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, st);
-    case CSR_RSSQ: return launch_sell_mode<CSR_RSSQ>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, st);
+    case CSR_RESID: return launch_sell_mode<CSR_RESID>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, nullptr, 0, st);
+    case CSR_JACOBI: return launch_sell_mode<CSR_JACOBI>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, nullptr, 0, st);
+    case CSR_SPMV: return launch_sell_mode<CSR_SPMV>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, nullptr, 0, st);
+    case CSR_RSSQ: return launch_sell_mode<CSR_RSSQ>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, nullptr, 0, st);
   }
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_sell_jacobi_prolong(int64_t n, int max_width, const int64_t* soff,
+                                      const int32_t* scol, const double* sval, const double* u,
+                                      const double* uH, int64_t nH, const double* f, double* out,
+                                      double omega, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (n >= ((int64_t)1 << 31) - 256 || nH < 1) return hipErrorInvalidValue;
+  return launch_sell_mode<CSR_JACOBI_P>(n, max_width, soff, scol, sval, u, f, out, omega, nullptr,
+                                        0, n, uH, nH, st);
 }
 
 hipError_t launch_sell_gs_color(int64_t n_storage, int max_width, const int64_t* soff,
@@ -315,7 +348,7 @@ hipError_t launch_sell_gs_color(int64_t n_storage, int max_width, const int64_t*
   if (count <= 0) return hipSuccess;
   if (n_storage >= ((int64_t)1 << 31) - 256 || (row0 & 63)) return hipErrorInvalidValue;
   return launch_sell_mode<CSR_GS>(n_storage, max_width, soff, scol, sval, u, f, u, 1.0, rowid,
-                                  row0, count, st);
+                                  row0, count, nullptr, 0, st);
 }
 
 // Device-side scan of the row pointer for the two launch parameters above
@@ -394,6 +427,27 @@ hipError_t launch_linear_prolong_add(int64_t n_h, int64_t n_H, const double* uH,
   if (n_h <= 0) return hipSuccess;
   hipLaunchKernelGGL(linear_prolong_add_kernel, dim3((unsigned)((n_h + 255) / 256)),
                      dim3(256), 0, st, n_h, n_H, uH, uh);
+  return hipGetLastError();
+}
+
+// First Jacobi sweep from a zero guess (coarse levels on the way down,
+// multigrid.hpp:278 then :268): with u == 0 every a_ij*u_j is +-0 and the row sum
+// is +0.0, so the sweep needs only f and the diagonal -- same operations, same
+// bits as the full kernel on a zero vector, without streaming the matrix.
+__global__ __launch_bounds__(256) void jacobi_from_zero_kernel(
+    int64_t n, const double* __restrict__ diag, const double* __restrict__ f,
+    double* __restrict__ out, double omega) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double xi = 0.0, acc = 0.0;
+  const double d = diag[i], fi = f[i];
+  out[i] = (d == 0.0) ? xi : xi + omega * ((fi - acc) / d - xi);
+}
+hipError_t launch_jacobi_from_zero(int64_t n, const double* diag, const double* f, double* out,
+                                   double omega, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(jacobi_from_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     st, n, diag, f, out, omega);
   return hipGetLastError();
 }
 

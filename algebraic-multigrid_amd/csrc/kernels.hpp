@@ -10,7 +10,8 @@ enum CsrMode {
   CSR_JACOBI = 1,  // out = x_i + omega*((f_i - sum_{j!=i} a_ij x_j)/a_ii - x_i)
   CSR_SPMV = 2,    // out = A x
   CSR_RSSQ = 3,    // out_i = (f_i - (A x)_i)^2
-  CSR_GS = 4       // in-place Gauss-Seidel update of one colour (K-SELL only)
+  CSR_GS = 4,      // in-place Gauss-Seidel update of one colour (K-SELL only)
+  CSR_JACOBI_P = 5 // Jacobi sweep whose input is x + P*uH (linear P), K-SELL only
 };
 
 // max_block_nnz: max entries in any 256-row block; max_row_nnz: longest row.
@@ -23,6 +24,16 @@ hipError_t launch_csr(int mode, int64_t n, int64_t nnz, int max_block_nnz,
 hipError_t launch_sell(int mode, int64_t n, int max_width, const int64_t* soff,
                        const int32_t* scol, const double* sval, const double* x,
                        const double* f, double* out, double omega, hipStream_t st);
+// out = Jacobi sweep applied to (u + P uH), P = LinearInterpolator prolongation:
+// prolongation + add (multigrid.hpp:294-296) fused into the first post-smoothing
+// sweep; u itself is not modified.
+hipError_t launch_sell_jacobi_prolong(int64_t n, int max_width, const int64_t* soff,
+                                      const int32_t* scol, const double* sval, const double* u,
+                                      const double* uH, int64_t nH, const double* f, double* out,
+                                      double omega, hipStream_t st);
+// out = Jacobi sweep applied to u == 0: needs only the diagonal and f.
+hipError_t launch_jacobi_from_zero(int64_t n, const double* diag, const double* f, double* out,
+                                   double omega, hipStream_t st);
 // One colour of the multicolour Gauss-Seidel: storage rows [row0, row0+count) of a
 // colour-permuted SELL-64 matrix (row0 % 64 == 0), rowid = dof of each storage
 // row (-1 pads); u[rowid] = (f - sum_{j != i} a_ij u_j) / a_ii in place.

@@ -122,6 +122,38 @@ struct DevMat {
 
 int g_default_layout = AMG_HIP_LAYOUT_AUTO;
 
+// Device copies drop entries that are exactly 0.0 (the Galerkin product keeps
+// them structurally, SURVEY F5: 22 % of level 1).  x + 0*u == x for every finite
+// u, so results are bit-identical; the host hierarchy (getters) keeps them.
+Sparse without_exact_zeros(const Sparse& M) {
+  Sparse R;
+  R.n_outer = M.n_outer;
+  R.n_inner = M.n_inner;
+  R.ptr.assign(M.n_outer + 1, 0);
+  R.idx.reserve(M.idx.size());
+  R.val.reserve(M.val.size());
+  for (int64_t o = 0; o < M.n_outer; ++o) {
+    for (int32_t p = M.ptr[o]; p < M.ptr[o + 1]; ++p)
+      if (M.val[p] != 0.0) {
+        R.idx.push_back(M.idx[p]);
+        R.val.push_back(M.val[p]);
+      }
+    R.ptr[o + 1] = (int32_t)R.idx.size();
+  }
+  return R;
+}
+
+hipError_t upload_mat(const Sparse& M, int layout, DevMat* D);
+
+hipError_t upload_mat_pruned(const Sparse& M, int layout, bool prune, DevMat* D) {
+  if (!prune) return upload_mat(M, layout, D);
+  bool any = false;
+  for (double v : M.val)
+    if (v == 0.0) { any = true; break; }
+  if (!any) return upload_mat(M, layout, D);
+  return upload_mat(without_exact_zeros(M), layout, D);
+}
+
 // layout: AMG_HIP_LAYOUT_*; AUTO takes SELL-64 unless padding exceeds 25 %.
 hipError_t upload_mat(const Sparse& M, int layout, DevMat* D) {
   D->n_rows = M.n_outer;
@@ -189,6 +221,7 @@ struct Level {
   bool symmetric = false;  //   smoother.hpp:101-117); aliases A_rows when bitwise equal
   const DevMat& A_cols() const { return symmetric ? A_rows : A_cols_own; }
   DevMem u, f, r, tmp;
+  DevMem diag;             // a_ii (true-Jacobi smoother only)
   // transfers to level+1 (absent on the coarsest level)
   Sparse P_csc, R_csc;
   bool linear = false;
@@ -232,7 +265,19 @@ namespace {
 // ---- smoother on one level --------------------------------------------------
 amg_hip_status enqueue_multicolor(amg_hip_solver* s, Level& L, hipStream_t st);
 
-amg_hip_status enqueue_smooth(amg_hip_solver* s, int l) {
+// phase 0: u_l is arbitrary.  phase 1: u_l is known to be zero (pre-smoothing of a
+// coarse level, multigrid.hpp:278).  phase 2: u_l still lacks the correction
+// P u_{l+1} (multigrid.hpp:294-296), the smoother must apply it.  Only the true
+// Jacobi smoother has shortcuts for phases 1/2; callers fall back otherwise.
+bool jacobi_fuses_zero(const amg_hip_solver* s) {
+  return s->opt.smoother == AMG_HIP_SM_JACOBI && !s->opt.no_fusion && s->opt.smoother_iters >= 1;
+}
+bool jacobi_fuses_prolong(const amg_hip_solver* s, int l) {
+  const Level& L = s->lv[l];
+  return jacobi_fuses_zero(s) && L.linear && s->opt.stencil_transfers && L.A_cols().sell;
+}
+
+amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0) {
   Level& L = s->lv[l];
   hipStream_t st = s->stream;
   const int iters = s->opt.smoother_iters;
@@ -255,7 +300,22 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l) {
       const DevMat& A = L.A_cols();
       double* a = L.u.as<double>();
       double* b = L.tmp.as<double>();
-      for (int it = 0; it < iters; ++it) {
+      int it = 0;
+      if (phase == 1 && jacobi_fuses_zero(s)) {
+        HIP_TRY(launch_jacobi_from_zero(L.n, L.diag.as<double>(), L.f.as<double>(), b,
+                                        s->opt.omega, st));
+        std::swap(a, b);
+        it = 1;
+      } else if (phase == 2 && jacobi_fuses_prolong(s, l)) {
+        Level& C = s->lv[l + 1];
+        HIP_TRY(launch_sell_jacobi_prolong(A.n_rows, A.max_width, A.soff.as<int64_t>(),
+                                           A.scol.as<int32_t>(), A.sval.as<double>(), a,
+                                           C.u.as<double>(), C.n, L.f.as<double>(), b,
+                                           s->opt.omega, st));
+        std::swap(a, b);
+        it = 1;
+      }
+      for (; it < iters; ++it) {
         HIP_TRY(launch_mat(CSR_JACOBI, A, a, L.f.as<double>(), b, s->opt.omega, st));
         std::swap(a, b);
       }
@@ -299,18 +359,21 @@ amg_hip_status enqueue_residual(amg_hip_solver* s, int l) {
 amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
   const int nl = (int)s->lv.size();
   hipStream_t st = s->stream;
+  const bool zero_known = jacobi_fuses_zero(s);  // coarse pre-smoothing starts from u == 0
   for (int l = 0; l < nl; ++l) {
-    amg_hip_status r = enqueue_smooth(s, l);                       // :268
+    amg_hip_status r = enqueue_smooth(s, l, (l >= 1 && zero_known) ? 1 : 0);  // :268
     if (r != AMG_HIP_OK) return r;
     if ((r = enqueue_residual(s, l)) != AMG_HIP_OK) return r;      // :272-274
     if (l + 1 != nl) {
       Level& L = s->lv[l];
       Level& C = s->lv[l + 1];
+      // :278 -- when the smoother starts from "u == 0" without reading u, the
+      // fill itself is dead (u_{l+1} is fully overwritten before anyone reads it)
       if (L.linear && s->opt.stencil_transfers) {                  // :278 + :281-282
         HIP_TRY(launch_linear_restrict(L.n, C.n, L.r.as<double>(), C.f.as<double>(),
-                                       C.u.as<double>(), st));
+                                       zero_known ? nullptr : C.u.as<double>(), st));
       } else {
-        HIP_TRY(hipMemsetAsync(C.u.p, 0, sizeof(double) * C.n, st)); // :278
+        if (!zero_known) HIP_TRY(hipMemsetAsync(C.u.p, 0, sizeof(double) * C.n, st)); // :278
         const DevCsr& R = L.R_rows;
         HIP_TRY(launch_csr(CSR_SPMV, R.n_rows, R.nnz, R.max_block_nnz, R.max_row_nnz,
                            R.rowptr(), R.col(), R.v(), L.r.as<double>(), nullptr,
@@ -327,6 +390,11 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
   for (int l = nl - 2; l >= 0; --l) {                              // :291
     Level& L = s->lv[l];
     Level& C = s->lv[l + 1];
+    if (jacobi_fuses_prolong(s, l)) {                              // :294-296 inside :300
+      amg_hip_status r = enqueue_smooth(s, l, 2);
+      if (r != AMG_HIP_OK) return r;
+      continue;
+    }
     if (L.linear && s->opt.stencil_transfers) {                    // :294-296
       HIP_TRY(launch_linear_prolong_add(L.n, C.n, C.u.as<double>(), L.u.as<double>(), st));
     } else {
@@ -444,9 +512,17 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     Level& L = s->lv[l];
     L.symmetric = same_arrays(A_r, L.A_csc);
     if (dev) {
-    HIP_TRY(upload_mat(A_r, s->opt.layout, &L.A_rows));
+    const bool prune = !s->opt.keep_structural_zeros;
+    HIP_TRY(upload_mat_pruned(A_r, s->opt.layout, prune, &L.A_rows));
     if (!L.symmetric && s->opt.smoother >= AMG_HIP_SM_JACOBI)
-      HIP_TRY(upload_mat(L.A_csc, s->opt.layout, &L.A_cols_own));
+      HIP_TRY(upload_mat_pruned(L.A_csc, s->opt.layout, prune, &L.A_cols_own));
+    if (s->opt.smoother == AMG_HIP_SM_JACOBI) {  // diagonal of the column-as-row walk
+      std::vector<double> dg(L.n, 0.0);
+      for (int64_t c = 0; c < L.n; ++c)
+        for (int32_t p = L.A_csc.ptr[c]; p < L.A_csc.ptr[c + 1]; ++p)
+          if (L.A_csc.idx[p] == c) dg[c] = L.A_csc.val[p];
+      HIP_TRY(upload(L.diag, dg.data(), dg.size()));
+    }
     HIP_TRY(L.u.alloc(sizeof(double) * L.n));
     HIP_TRY(L.f.alloc(sizeof(double) * L.n));
     HIP_TRY(L.r.alloc(sizeof(double) * L.n));
@@ -578,6 +654,8 @@ void amg_hip_default_options(amg_hip_options* o) {
   o->use_graph = 1;
   o->stencil_transfers = 1;
   o->layout = g_default_layout;
+  o->keep_structural_zeros = 0;
+  o->no_fusion = 0;
 }
 
 void amg_hip_set_default_layout(int32_t layout) {

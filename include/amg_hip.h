@@ -77,7 +77,16 @@ typedef struct {
                               touched); getters work, compute entry points fail.
                               Used by the row-block multi-GPU driver, where every
                               rank slices its own rows out of the hierarchy.       */
-  int32_t reserved[6];
+  int32_t keep_structural_zeros; /* 0 (default): device copies of the level matrices
+                              drop entries that are exactly 0.0 (Eigen's Galerkin
+                              product keeps them, 22 % of level 1); results are
+                              bit-identical, the getters still return them.       */
+  int32_t no_fusion;       /* 0 (default): the true-Jacobi V-cycle (a) takes the first
+                              pre-smoothing sweep of a coarse level, whose input is the
+                              zero vector, from f and the diagonal alone, (b) applies
+                              the prolongation inside the first post-smoothing sweep.
+                              Same operations on the same values: bit-identical.  */
+  int32_t reserved[4];
 } amg_hip_options;
 
 typedef struct amg_hip_solver amg_hip_solver; /* opaque; owns device memory    */

@@ -436,3 +436,35 @@ def test_multicolor_gs_two_iterations_3d(amg, oracle):
         mg.vcycle()
     assert np.array_equal(mg.get_soln(0), ref.get_vec(0, "u"))
     mg.close()
+
+
+def test_jacobi_fusions_and_zero_pruning_are_bit_neutral(amg, oracle):
+    """The true-Jacobi V-cycle shortcuts (first coarse pre-sweep from the diagonal
+    alone, prolongation applied inside the first post-sweep, exact-zero entries
+    dropped from the device copies) must not change a single bit."""
+    n, L = 80, 6
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
+    variants = [dict(), dict(no_fusion=True), dict(keep_structural_zeros=True),
+                dict(no_fusion=True, keep_structural_zeros=True), dict(stencil_transfers=False)]
+    mgs = [amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6, **kw)
+           for kw in variants]
+    for c in range(4):
+        ref.vcycle()
+        for mg in mgs:
+            mg.vcycle()
+        for l in range(L):
+            want = ref.get_vec(l, "u")
+            for k, mg in enumerate(mgs):
+                assert np.array_equal(mg.get_soln(l), want), (c, l, variants[k])
+                assert np.array_equal(mg.get_residual(l), ref.get_vec(l, "r")), (c, l, variants[k])
+    for mg in mgs:
+        mg.close()
+    # one sweep per smooth(): the fused sweep is also the last one
+    ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=1, omega=0.5)
+    mg = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=1, omega=0.5)
+    for _ in range(3):
+        ref.vcycle()
+        mg.vcycle()
+    assert np.array_equal(mg.get_soln(0), ref.get_vec(0, "u"))
+    mg.close()
