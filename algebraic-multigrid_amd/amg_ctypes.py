@@ -35,7 +35,8 @@ class Options(C.Structure):
                 ("omega", C.c_double), ("device", C.c_int32), ("use_graph", C.c_int32),
                 ("stencil_transfers", C.c_int32), ("layout", C.c_int32),
                 ("host_only", C.c_int32), ("keep_structural_zeros", C.c_int32),
-                ("no_fusion", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("no_fusion", C.c_int32), ("fuse_prolong", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 # name -> (restype, argtypes).  Must list EVERY symbol include/amg_hip.h declares
@@ -173,7 +174,7 @@ class Multigrid:
                  smoother_iters=1, omega=1.0, tolerance=1e-9, compute_error_every_n_iters=10,
                  n_iters=100, device=-1, use_graph=True, stencil_transfers=True,
                  transfers=None, layout=None, host_only=False, keep_structural_zeros=False,
-                 no_fusion=False):
+                 no_fusion=False, fuse_prolong=False):
         # multigrid.hpp:165-178 (same checks, same order)
         if compute_error_every_n_iters > n_iters:
             raise ValueError("`compute_error_every_n_iters` must be leq to `n_iters`, got "
@@ -195,6 +196,7 @@ class Multigrid:
         o.host_only = int(host_only)
         o.keep_structural_zeros = int(keep_structural_zeros)
         o.no_fusion = int(no_fusion)
+        o.fuse_prolong = int(fuse_prolong)
         h = C.c_void_p()
         if transfers is None:
             st = lib().amg_hip_create(n, _p32(colptr), _p32(rowind), _p64(val), _p64(b),

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
 #include <utility>
 
 #include "kernels.hpp"
@@ -207,7 +208,7 @@ hipError_t launch_csr(int mode, int64_t n, int64_t nnz, int max_block_nnz,
 // [row0, row0 + count) of the matrix, rowid[p] is the dof each one updates
 // (-1 = padding), x is updated IN PLACE -- rows of one colour do not reference
 // each other, so the launch is race-free.
-template <int MODE, int U>
+template <int MODE>
 __global__ __launch_bounds__(256) void sell_kernel(
     int n, const int64_t* __restrict__ soff, const int32_t* __restrict__ scol,
     const double* __restrict__ sval, const double* x, const double* __restrict__ f,
@@ -251,22 +252,24 @@ __global__ __launch_bounds__(256) void sell_kernel(
   }
   double acc = (MODE == CSR_RESID) ? fi : 0.0;
   double diag = 0.0;
-  for (int j0 = 0; j0 < w; j0 += U) {
-    int32_t c[U];
-    double v[U], xx[U];
+  // one pass over U entries: all loads of the pass are issued before the first use
+  auto pass = [&](int j0, auto UU) {
+    constexpr int UN = decltype(UU)::value;
+    int32_t c[UN];
+    double v[UN], xx[UN];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const int j = j0 + u < w ? j0 + u : j0;
       c[u] = scol[base + ((int64_t)j << 6)];
       v[u] = sval[base + ((int64_t)j << 6)];
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < UN; ++u) {
       if (MODE == CSR_JACOBI_P) xx[u] = corrected(c[u] >= 0 ? c[u] : 0);
       else xx[u] = x[c[u] >= 0 ? c[u] : 0];
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < UN; ++u) {
       if (j0 + u < w && c[u] >= 0) {
         if (MODE == CSR_RESID) {
           acc -= v[u] * xx[u];
@@ -278,7 +281,15 @@ __global__ __launch_bounds__(256) void sell_kernel(
         }
       }
     }
-  }
+  };
+  // the pass length follows the PANEL's width (wave-uniform branch): a 7-wide
+  // panel walked with a 9-entry pass would issue 2 dead loads + 2 dead gathers
+  if (w <= 3) pass(0, std::integral_constant<int, 3>{});
+  else if (w <= 5) pass(0, std::integral_constant<int, 5>{});
+  else if (w <= 7) pass(0, std::integral_constant<int, 7>{});
+  else if (w <= 9) pass(0, std::integral_constant<int, 9>{});
+  else
+    for (int j0 = 0; j0 < w; j0 += 8) pass(j0, std::integral_constant<int, 8>{});
   if (live) {
     if (MODE == CSR_RESID || MODE == CSR_SPMV) {
       out[row] = acc;
@@ -293,29 +304,16 @@ __global__ __launch_bounds__(256) void sell_kernel(
   }
 }
 
-template <int MODE, int U>
-static hipError_t launch_sell_u(int64_t n, const int64_t* soff, const int32_t* scol,
-                                const double* sval, const double* x, const double* f,
-                                double* out, double omega, const int32_t* rowid, int64_t row0,
-                                int64_t count, const double* uH, int64_t nH, hipStream_t st) {
-  const unsigned grid = (unsigned)((count + 255) / 256);
-  hipLaunchKernelGGL((sell_kernel<MODE, U>), dim3(grid), dim3(256), 0, st, (int)n, soff, scol,
-                     sval, x, f, out, omega, rowid, (int)row0, uH, (int)nH);
-  return hipGetLastError();
-}
 template <int MODE>
-static hipError_t launch_sell_mode(int64_t n, int max_width, const int64_t* soff,
+static hipError_t launch_sell_mode(int64_t n, int /*max_width*/, const int64_t* soff,
                                    const int32_t* scol, const double* sval, const double* x,
                                    const double* f, double* out, double omega,
                                    const int32_t* rowid, int64_t row0, int64_t count,
                                    const double* uH, int64_t nH, hipStream_t st) {
-#define AMG_SELL_U(UU) launch_sell_u<MODE, UU>(n, soff, scol, sval, x, f, out, omega, rowid, row0, count, uH, nH, st)
-  if (max_width <= 3) return AMG_SELL_U(3);
-  if (max_width <= 5) return AMG_SELL_U(5);
-  if (max_width <= 7) return AMG_SELL_U(7);
-  if (max_width <= 9) return AMG_SELL_U(9);
-  return AMG_SELL_U(8);
-#undef AMG_SELL_U
+  const unsigned grid = (unsigned)((count + 255) / 256);
+  hipLaunchKernelGGL((sell_kernel<MODE>), dim3(grid), dim3(256), 0, st, (int)n, soff, scol, sval,
+                     x, f, out, omega, rowid, (int)row0, uH, (int)nH);
+  return hipGetLastError();
 }
 hipError_t launch_sell(int mode, int64_t n, int max_width, const int64_t* soff,
                        const int32_t* scol, const double* sval, const double* x,
@@ -422,11 +420,39 @@ hipError_t launch_linear_restrict(int64_t n_h, int64_t n_H, const double* r, dou
                      dim3(256), 0, st, n_h, n_H, r, fH, uH_zero);
   return hipGetLastError();
 }
+// Two fine rows (2j, 2j+1) per lane: 16-byte load/store of u, same arithmetic.
+__global__ __launch_bounds__(256) void linear_prolong_add2_kernel(
+    int64_t n_h, int64_t n_H, const double* __restrict__ uH, double* __restrict__ uh) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = 2 * j;
+  if (i >= n_h) return;
+  double t0 = 0.0, t1 = 0.0;
+  const double b = (j < n_H) ? uH[j] : 0.0;
+  if (j >= 1 && j - 1 < n_H) t0 += 0.5 * uH[j - 1];
+  if (j < n_H) {
+    t0 += 0.5 * b;
+    t1 += 1.0 * b;
+  }
+  if (i + 1 < n_h) {
+    double2 u = *reinterpret_cast<const double2*>(uh + i);
+    u.x = u.x + t0;
+    u.y = u.y + t1;
+    *reinterpret_cast<double2*>(uh + i) = u;
+  } else {
+    uh[i] = uh[i] + t0;
+  }
+}
 hipError_t launch_linear_prolong_add(int64_t n_h, int64_t n_H, const double* uH,
                                      double* uh, hipStream_t st) {
   if (n_h <= 0) return hipSuccess;
-  hipLaunchKernelGGL(linear_prolong_add_kernel, dim3((unsigned)((n_h + 255) / 256)),
-                     dim3(256), 0, st, n_h, n_H, uH, uh);
+  if ((reinterpret_cast<uintptr_t>(uh) & 15) == 0) {
+    const int64_t nt = (n_h + 1) / 2;
+    hipLaunchKernelGGL(linear_prolong_add2_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256),
+                       0, st, n_h, n_H, uH, uh);
+  } else {
+    hipLaunchKernelGGL(linear_prolong_add_kernel, dim3((unsigned)((n_h + 255) / 256)),
+                       dim3(256), 0, st, n_h, n_H, uH, uh);
+  }
   return hipGetLastError();
 }
 

@@ -132,7 +132,7 @@ def run_single(args):
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "sell_kernel<CSR_JACOBI,5> (level-0 Jacobi sweep, SELL-64 panels)",
+            "kernel": "sell_kernel<CSR_JACOBI> (level-0 Jacobi sweep, SELL-64 panels)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -81,12 +81,13 @@ typedef struct {
                               drop entries that are exactly 0.0 (Eigen's Galerkin
                               product keeps them, 22 % of level 1); results are
                               bit-identical, the getters still return them.       */
-  int32_t no_fusion;       /* 0 (default): the true-Jacobi V-cycle (a) takes the first
+  int32_t no_fusion;       /* 0 (default): the true-Jacobi V-cycle takes the first
                               pre-smoothing sweep of a coarse level, whose input is the
-                              zero vector, from f and the diagonal alone, (b) applies
-                              the prolongation inside the first post-smoothing sweep.
-                              Same operations on the same values: bit-identical.  */
-  int32_t reserved[4];
+                              zero vector, from f and the diagonal alone.  Same
+                              operations on the same values: bit-identical.       */
+  int32_t fuse_prolong;    /* 1: apply the prolongation inside the first post-smoothing
+                              Jacobi sweep (bit-identical; measured slower, off)  */
+  int32_t reserved[3];
 } amg_hip_options;
 
 typedef struct amg_hip_solver amg_hip_solver; /* opaque; owns device memory    */

@@ -445,7 +445,7 @@ def test_jacobi_fusions_and_zero_pruning_are_bit_neutral(amg, oracle):
     n, L = 80, 6
     A, b = oracle.laplacian(n), oracle.rhs(n)
     ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
-    variants = [dict(), dict(no_fusion=True), dict(keep_structural_zeros=True),
+    variants = [dict(), dict(no_fusion=True), dict(keep_structural_zeros=True), dict(fuse_prolong=True),
                 dict(no_fusion=True, keep_structural_zeros=True), dict(stencil_transfers=False)]
     mgs = [amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6, **kw)
            for kw in variants]
