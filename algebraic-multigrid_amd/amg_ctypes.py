@@ -36,7 +36,7 @@ class Options(C.Structure):
                 ("stencil_transfers", C.c_int32), ("layout", C.c_int32),
                 ("host_only", C.c_int32), ("keep_structural_zeros", C.c_int32),
                 ("no_fusion", C.c_int32), ("fuse_prolong", C.c_int32),
-                ("reserved", C.c_int32 * 3)]
+                ("reserved", C.c_int32 * 3), ("stream", C.c_void_p)]
 
 
 # name -> (restype, argtypes).  Must list EVERY symbol include/amg_hip.h declares
@@ -93,6 +93,8 @@ _SIGS = {
                                      C.c_double, C.c_int64, C.c_void_p]),
     "amg_hip_dev_spmv": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "amg_hip_dev_jacobi_from_zero": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_double, C.c_void_p]),
     "amg_hip_dev_axpy1": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "amg_hip_dev_sumsq": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -174,7 +176,7 @@ class Multigrid:
                  smoother_iters=1, omega=1.0, tolerance=1e-9, compute_error_every_n_iters=10,
                  n_iters=100, device=-1, use_graph=True, stencil_transfers=True,
                  transfers=None, layout=None, host_only=False, keep_structural_zeros=False,
-                 no_fusion=False, fuse_prolong=False):
+                 no_fusion=False, fuse_prolong=False, stream=None):
         # multigrid.hpp:165-178 (same checks, same order)
         if compute_error_every_n_iters > n_iters:
             raise ValueError("`compute_error_every_n_iters` must be leq to `n_iters`, got "
@@ -197,6 +199,8 @@ class Multigrid:
         o.keep_structural_zeros = int(keep_structural_zeros)
         o.no_fusion = int(no_fusion)
         o.fuse_prolong = int(fuse_prolong)
+        if stream:
+            o.stream = C.c_void_p(stream)
         h = C.c_void_p()
         if transfers is None:
             st = lib().amg_hip_create(n, _p32(colptr), _p32(rowind), _p64(val), _p64(b),

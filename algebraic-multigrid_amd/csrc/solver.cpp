@@ -242,6 +242,7 @@ struct amg_hip_solver {
   amg_hip_options opt;
   int device = 0;
   hipStream_t stream = nullptr;
+  bool own_stream = true;
   std::vector<Level> lv;
   // coarsest level factor
   int64_t band_n = 0, band_w = 0;
@@ -256,7 +257,7 @@ struct amg_hip_solver {
   ~amg_hip_solver() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream && own_stream) (void)hipStreamDestroy(stream);
   }
 };
 
@@ -497,7 +498,12 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
       HIP_TRY(hipGetDevice(&s->device));
     }
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    if (s->opt.stream) {
+      s->stream = (hipStream_t)s->opt.stream;
+      s->own_stream = false;
+    } else {
+      HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    }
   }
 
   const int nt = host_threads();
@@ -660,6 +666,7 @@ void amg_hip_default_options(amg_hip_options* o) {
   o->keep_structural_zeros = 0;
   o->no_fusion = 0;
   o->fuse_prolong = 0;
+  o->stream = nullptr;
 }
 
 void amg_hip_set_default_layout(int32_t layout) {
@@ -1210,6 +1217,12 @@ amg_hip_status amg_hip_dev_spmv(int64_t nrows, int64_t nnz, int32_t max_block_nn
                                 const double* val, const double* v, double* out, void* stream) {
   return dev_csr(CSR_SPMV, nrows, nnz, max_block_nnz, max_row_nnz, rowptr, col, val, v, nullptr,
                  out, 1.0, 0, stream);
+}
+amg_hip_status amg_hip_dev_jacobi_from_zero(int64_t nrows, const double* diag, const double* b,
+                                            double* u_out, double omega, void* stream) {
+  if (nrows < 0 || !diag || !b || !u_out) return fail(AMG_HIP_EINVAL, "bad argument");
+  HIP_TRY(launch_jacobi_from_zero(nrows, diag, b, u_out, omega, (hipStream_t)stream));
+  return AMG_HIP_OK;
 }
 amg_hip_status amg_hip_dev_axpy1(int64_t n, const double* x, double* y, void* stream) {
   if (n < 0 || !x || !y) return fail(AMG_HIP_EINVAL, "bad argument");

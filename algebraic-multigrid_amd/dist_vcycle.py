@@ -13,7 +13,8 @@ Exchanges (the only collectives on the data path):
     boundary unknowns its neighbours' rows reference (width = the level's half
     bandwidth m_l+1) with rank-1 / rank+1 -- grouped isend/irecv, KiB-sized;
   * restriction / prolongation need one remote entry per side (width-1 halo);
-  * when a level gets small (rows/rank below `agglomerate_rows`) its right-hand
+  * when a level gets small (fewer than `dist_min_rows` rows in total: the halo
+    exchanges then cost more than the sweeps they split) its right-hand
     side is all-gathered and every rank runs the rest of the V-cycle redundantly
     as an ordinary single-GPU solver on the sub-hierarchy (the C ABI solver with
     its hipGraph), then keeps its slice of the correction;
@@ -117,9 +118,13 @@ class HipBackend:
         self.lib = amg.lib()
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
+        # a dedicated (non-null) stream carries everything this rank does: kernels,
+        # the agglomerated solver's graph, and the waits of the collectives
+        self._stream = torch.cuda.Stream(self.device)
+        torch.cuda.set_stream(self._stream)
 
     def stream(self):
-        return torch.cuda.current_stream().cuda_stream
+        return self._stream.cuda_stream
 
     def vec(self, n):
         return torch.zeros(max(n, 1), dtype=torch.float64, device=self.device)[:n]
@@ -149,6 +154,10 @@ class HipBackend:
                   m["rowptr"].data_ptr(), m["col"].data_ptr(), m["val"].data_ptr(),
                   u_ext.data_ptr(), f.data_ptr(), r.data_ptr(), self.stream()))
 
+    def jacobi_from_zero(self, diag, b, u_out, omega):
+        self._chk(self.lib.amg_hip_dev_jacobi_from_zero(u_out.numel(), diag.data_ptr(),
+                  b.data_ptr(), u_out.data_ptr(), omega, self.stream()))
+
     def jacobi(self, m, u_ext, b, u_out, omega, diag_shift):
         self._chk(self.lib.amg_hip_dev_jacobi(m["n"], m["nnz"], m["mb"], m["mr"],
                   m["rowptr"].data_ptr(), m["col"].data_ptr(), m["val"].data_ptr(),
@@ -172,7 +181,7 @@ class HipBackend:
         return out.clone()
 
     def sync(self):
-        torch.cuda.current_stream().synchronize()
+        self._stream.synchronize()
 
     def tail(self, colptr, rowind, val, n_levels, omega, sweeps):
         """The agglomerated coarse part: an ordinary single-GPU solver."""
@@ -184,21 +193,20 @@ class _HipTail:
         amg = be.amg
         n = colptr.size - 1
         self.be = be
+        # same stream as the rest of the rank's work: no host synchronisation needed
         self.mg = amg.Multigrid(colptr, rowind, val, np.zeros(n), n_levels,
                                 smoother=amg.SM_JACOBI, smoother_iters=sweeps, omega=omega,
-                                device=be.device.index)
+                                device=be.device.index, stream=be.stream())
         self.n = n
 
     def cycle(self, f_full, u_full, zero_guess=True):
         """u_full = one V-cycle on the sub-hierarchy, rhs f_full; from a zero guess
         (multigrid.hpp:278) unless this is the whole hierarchy."""
-        self.be.sync()                              # f_full was produced on torch's stream
         self.mg.copy_vec_dev(0, "f", f_full.data_ptr(), True)
         if zero_guess:
             self.mg.zero_vec(0, "u")
         self.mg.vcycle(1)
         self.mg.copy_vec_dev(0, "u", u_full.data_ptr(), False)
-        self.mg.sync()                              # u_full is consumed on torch's stream
 
     def rss(self):
         return self.mg.rss()
@@ -213,7 +221,7 @@ class DistributedVcycle:
     """multigrid.hpp:263-305 over row-block shards (true Jacobi smoother)."""
 
     def __init__(self, hierarchy, b, backend, rank, world, omega=0.6, sweeps=2,
-                 agglomerate_rows=131072, group=None, host_staged=False):
+                 dist_min_rows=6000000, group=None, host_staged=False):
         """hierarchy: object with n_levels, get_n_dofs(l), get_coefficient_matrix(l)
         -> CSC (colptr, rowind, val) of the (symmetric) level matrix.
         host_staged: exchange through host buffers (a process group whose backend
@@ -239,7 +247,7 @@ class DistributedVcycle:
             rows_of = np.repeat(np.arange(sizes[l], dtype=np.int64), np.diff(cp))
             hb = int(np.abs(ri.astype(np.int64) - rows_of).max()) if ri.size else 0
             del rows_of
-            small = min(owned) < max(agglomerate_rows, 1) or min(owned) < hb + 2
+            small = sizes[l] < max(dist_min_rows, 1) or min(owned) < hb + 2
             last_possible = (l == L - 1)   # the coarsest level is always solved redundantly
             if small or last_possible:
                 break
@@ -256,6 +264,11 @@ class DistributedVcycle:
             D.n, D.s, D.e = sizes[l], s, e
             D.A = LocalMatrix(cp, ri, v, s, e)     # symmetric: CSC arrays == CSR arrays
             D.mat = backend.matrix(D.A.rowptr, D.A.col, D.A.val)
+            dg = np.zeros(e - s)                    # a_ii of the owned rows
+            rows_l = np.repeat(np.arange(e - s), np.diff(D.A.rowptr))
+            on_d = D.A.col == rows_l + D.A.diag_shift
+            dg[rows_l[on_d]] = D.A.val[on_d]
+            D.diag = backend.from_numpy(dg)
             n_ext = D.A.halo_lo + (e - s) + D.A.halo_hi
             D.u = backend.vec(n_ext)
             D.u2 = backend.vec(n_ext)
@@ -359,10 +372,16 @@ class DistributedVcycle:
         self._exchange(vec, n_owned, 1, 1, 1, 1)
 
     # ---- smoother: `sweeps` two-buffer Jacobi passes on level l ----
-    def _smooth(self, l):
+    def _smooth(self, l, from_zero=False):
         D = self.lv[l]
         lo, n = D.A.halo_lo, D.e - D.s
-        for _ in range(self.sweeps):
+        for k in range(self.sweeps):
+            if k == 0 and from_zero:
+                # u_l == 0 (multigrid.hpp:278): the sweep needs f and the diagonal only,
+                # and no halo (same bits as the full sweep on zeros)
+                self.be.jacobi_from_zero(D.diag, D.f, D.u2[lo:lo + n], self.omega)
+                D.u, D.u2 = D.u2, D.u
+                continue
             self._exchange_u(l, D.u)
             self.be.jacobi(D.mat, D.u, D.f, D.u2[lo:lo + n], self.omega, D.A.diag_shift)
             D.u, D.u2 = D.u2, D.u
@@ -373,14 +392,15 @@ class DistributedVcycle:
         for l in range(nd):                                   # multigrid.hpp:265
             D = self.lv[l]
             lo, n = D.A.halo_lo, D.e - D.s
-            self._smooth(l)                                   # :268
+            self._smooth(l, from_zero=(l >= 1 and self.sweeps >= 1))  # :268
             self._exchange_u(l, D.u)
             be.residual(D.mat, D.u, D.f, D.r[1:1 + n])       # :272-274
             self._exchange_1(D.r, n)
             nH = D.ce - D.cs
             if l + 1 < nd:                                    # :278, :281-282
                 C = self.lv[l + 1]
-                C.u.zero_()
+                if self.sweeps < 1:
+                    C.u.zero_()
                 be.spmv(D.R, D.r, C.f)
             else:
                 be.spmv(D.R, D.r, self.gather_in[:nH])
@@ -449,9 +469,16 @@ def bench(args):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world,
-                            device_id=torch.device("cuda", local))
+    # AMG_DIST_REHEARSAL=1: every rank on GPU 0, gloo + host-staged exchange.  Only for
+    # rehearsing this code path on a one-GPU box (RCCL refuses two ranks on one device).
+    rehearsal = os.environ.get("AMG_DIST_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
     be = HipBackend(local)
     from bench import n_levels_for, HBM_PEAK_GBS
     t0 = time.time()
@@ -462,7 +489,7 @@ def bench(args):
                          smoother_iters=args.sweeps, omega=args.omega, host_only=True)
     del colptr, rowind, val
     dv = DistributedVcycle(hier, b, be, rank, world, omega=args.omega, sweeps=args.sweeps,
-                           agglomerate_rows=args.agglomerate_rows)
+                           dist_min_rows=args.dist_min_rows, host_staged=rehearsal)
     hier.close()
     setup_s = time.time() - t0
     for _ in range(args.warmup):
@@ -477,7 +504,8 @@ def bench(args):
     be.sync()
     dist.barrier()
     be.sync()
-    dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=be.device)
+    dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64,
+                      device="cpu" if rehearsal else be.device)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
     rss = dv.rss()
@@ -487,9 +515,9 @@ def bench(args):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.profile_launches)]
     for a, c in ev:
-        a.record()
+        a.record(be._stream)
         be.jacobi(D.mat, D.u, D.f, D.u2[lo:lo + n], dv.omega, D.A.diag_shift)
-        c.record()
+        c.record(be._stream)
     be.sync()
     ms = [a.elapsed_time(c) for a, c in ev]
     avg_ms = sum(ms) / len(ms)
@@ -510,8 +538,8 @@ def bench(args):
                              f"omega={args.omega} {args.sweeps}+{args.sweeps} sweeps, {L}-level V-cycle, "
                              f"row-block shards over {world} GPUs ({dv.n_dist} distributed levels, "
                              f"rest agglomerated), fp64"),
-                "n": args.n, "levels": L, "distributed_levels": dv.n_dist,
-                "agglomerate_rows": args.agglomerate_rows, "setup_seconds": setup_s,
+                "n": args.n, "levels": L, "distributed_levels": dv.n_dist, "rehearsal": rehearsal,
+                "dist_min_rows": args.dist_min_rows, "setup_seconds": setup_s,
                 "rss_after_warmup": rss0, "rss_after_steps": rss,
             },
             "roofline": {

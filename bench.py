@@ -168,8 +168,8 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=2048, help="grid of the CPU baseline sample")
     ap.add_argument("--cpu-cycles", type=int, default=5)
     ap.add_argument("--profile-launches", type=int, default=40)
-    ap.add_argument("--agglomerate-rows", type=int, default=131072,
-                    help="multi-GPU: levels with fewer rows per rank run redundantly on every rank")
+    ap.add_argument("--dist-min-rows", type=int, default=6000000,
+                    help="multi-GPU: levels with fewer rows (in total) run redundantly on every rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -88,6 +88,11 @@ typedef struct {
   int32_t fuse_prolong;    /* 1: apply the prolongation inside the first post-smoothing
                               Jacobi sweep (bit-identical; measured slower, off)  */
   int32_t reserved[3];
+  void* stream;            /* hipStream_t to run on; NULL (default) = the solver creates
+                              and owns a non-blocking stream.  A caller that already
+                              orders its device work on a stream (torch's current
+                              stream in the multi-GPU driver) passes it here so that
+                              no host synchronisation is needed between the two.   */
 } amg_hip_options;
 
 typedef struct amg_hip_solver amg_hip_solver; /* opaque; owns device memory    */
@@ -284,6 +289,11 @@ amg_hip_status amg_hip_dev_spmv(int64_t nrows, int64_t nnz, int32_t max_block_nn
                                 int32_t max_row_nnz, const int32_t* rowptr,
                                 const int32_t* col, const double* val,
                                 const double* v, double* out, void* stream);
+/* First Jacobi sweep from a zero vector: u_out[i] = 0 + omega*((b[i] - 0)/diag[i] - 0)
+ * (diag[i] == 0 leaves 0); bit-identical to amg_hip_dev_jacobi on u_in == 0.   */
+amg_hip_status amg_hip_dev_jacobi_from_zero(int64_t nrows, const double* diag,
+                                            const double* b, double* u_out,
+                                            double omega, void* stream);
 /* y[i] += x[i] */
 amg_hip_status amg_hip_dev_axpy1(int64_t n, const double* x, double* y, void* stream);
 /* *out (device double) = sum_i r[i]^2 ; scratch >= 8 KiB device memory */

@@ -67,6 +67,12 @@ class CpuBackend:
             new = uk + omega * ((b.numpy() - acc) / diag - uk)
         u_out.copy_(torch.from_numpy(np.where(diag == 0.0, uk, new)))
 
+    def jacobi_from_zero(self, diag, b, u_out, omega):
+        d = diag.numpy()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            new = 0.0 + omega * ((b.numpy() - 0.0) / d - 0.0)
+        u_out.copy_(torch.from_numpy(np.where(d == 0.0, 0.0, new)))
+
     def spmv(self, m, v_ext, out):
         v = v_ext.numpy()
         acc = np.zeros(m.n)

@@ -60,7 +60,7 @@ def _worker(rank, world, port, n, L, cycles, agg, sweeps, omega, out_dir, use_pr
     else:
         be = CpuBackend(O)
     dv = dist_vcycle.DistributedVcycle(hier, b, be, rank, world, omega=omega,
-                                       sweeps=sweeps, agglomerate_rows=agg, host_staged=gpu)
+                                       sweeps=sweeps, dist_min_rows=agg, host_staged=gpu)
     rss = []
     for _ in range(cycles):
         dv.vcycle()
@@ -82,7 +82,7 @@ def _run(tmp_path, world, n, L, cycles, agg, sweeps=2, omega=0.6, product_hier=T
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_vcycle_equals_single_process(tmp_path, oracle, world):
     n, L, cycles = 48, 6, 3
-    got = _run(tmp_path, world, n, L, cycles, agg=100)
+    got = _run(tmp_path, world, n, L, cycles, agg=250)
     assert int(got["n_dist"]) >= 3          # several levels really are distributed
     A, b = oracle.laplacian(n), oracle.rhs(n)
     ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
@@ -95,7 +95,7 @@ def test_sharded_vcycle_equals_single_process(tmp_path, oracle, world):
 def test_sharded_odd_sizes_and_odd_sweeps(tmp_path, oracle):
     # odd grid (ragged line ends, odd/even block boundaries), 3 sweeps (buffers swap roles)
     n, L, cycles = 37, 5, 2
-    got = _run(tmp_path, 2, n, L, cycles, agg=60, sweeps=3, omega=0.5, product_hier=False)
+    got = _run(tmp_path, 2, n, L, cycles, agg=150, sweeps=3, omega=0.5, product_hier=False)
     A, b = oracle.laplacian(n), oracle.rhs(n)
     ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=3, omega=0.5)
     for _ in range(cycles):
@@ -140,7 +140,7 @@ def test_sharded_vcycle_hip_kernels_on_one_gpu(tmp_path, oracle, world):
     solver): `world` processes share GPU 0 and exchange through gloo/host
     buffers.  Everything except the RCCL transport itself runs as on N GPUs."""
     n, L, cycles = 96, 7, 3
-    got = _run(tmp_path, world, n, L, cycles, agg=300, gpu=True)
+    got = _run(tmp_path, world, n, L, cycles, agg=900, gpu=True)
     assert int(got["n_dist"]) >= 3
     A, b = oracle.laplacian(n), oracle.rhs(n)
     ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
