@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=4096, help="grid points per direction")
+    ap.add_argument("--grid", dest="n", type=int, default=4096, help="grid points per direction")
     ap.add_argument("--levels", type=int, default=0, help="0 = coarsest <= 511 dofs")
     ap.add_argument("--omega", type=float, default=0.6,
                     help="Jacobi relaxation; must stay below 2/lambda_max(D^-1 A) ~ 0.67 on the "
