@@ -551,53 +551,69 @@ __global__ __launch_bounds__(BLOCK) void gs_lex_window(
     const int row = slot_row[slot];
     const int depth = slot_depth[slot];
     const int wd = win_depth[w];
+    // per entry: kind 0 = absent / diagonal, 1 = term of the (first) sum, 2 = term
+    // of SOR's second sum (j > i, smoother.hpp:354-357); term = product that is
+    // already known (operand outside this window) or v * (value published in LDS).
+    // Everything is written branch-free (clamped addresses + selects) so that the
+    // loads of a phase are issued back to back instead of one wait per entry.
+    int sidx[MAXE];   // LDS slot of the in-window producer (0 when none)
+    bool dep[MAXE];
+    int kind[MAXE];
+    double v[MAXE], term[MAXE];
+    const bool live = row >= 0;
+    const int rowc = live ? row : 0;
+    const double bi = b[rowc];
+    const double uk = u[rowc];
+    double diag = 0.0;
     int32_t c[MAXE];
     int32_t sr[MAXE];
-    double v[MAXE], xg[MAXE];
-    double bi = 0.0, uk = 0.0;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
-      c[e] = -1;
-      sr[e] = -1;
-      v[e] = 0.0;
-      if (e < width && row >= 0) {
-        const int64_t at = (int64_t)e * n_slots + slot;
-        c[e] = ecol[at];
-        v[e] = eval[at];
-        sr[e] = esrc[at];
-      }
+      const int ee = e < width ? e : 0;
+      const int64_t at = (int64_t)ee * n_slots + slot;
+      c[e] = ecol[at];
+      v[e] = eval[at];
+      sr[e] = esrc[at];
     }
-    if (row >= 0) {
-      bi = b[row];
-      uk = u[row];
+    double ug[MAXE];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const bool entry = live && e < width && c[e] >= 0;
+      ug[e] = u[entry ? c[e] : 0];
     }
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e)
-      xg[e] = (c[e] >= 0 && sr[e] < 0) ? u[c[e]] : 0.0;
+    for (int e = 0; e < MAXE; ++e) {
+      const bool entry = live && e < width && c[e] >= 0;
+      const bool isdiag = entry && c[e] == row;
+      diag = isdiag ? v[e] : diag;
+      const bool off = entry && !isdiag;
+      dep[e] = off && sr[e] >= 0;
+      sidx[e] = dep[e] ? sr[e] : 0;
+      kind[e] = off ? ((mode == 2 && c[e] > row) ? 2 : 1) : 0;
+      term[e] = v[e] * ug[e];  // operand final (earlier window) or old value
+    }
     double unew = uk;
     for (int d = 0; d <= wd; ++d) {
-      if (row >= 0 && depth == d) {
-        double s = 0.0, s2 = 0.0, diag = 0.0;
+      double pv[MAXE];
 #pragma unroll
-        for (int e = 0; e < MAXE; ++e) {
-          if (c[e] >= 0) {
-            if (c[e] == row) {
-              diag = v[e];
-            } else {
-              const double xv = (sr[e] >= 0) ? pub[sr[e]] : xg[e];
-              if (mode == 2 && c[e] > row) s2 += v[e] * xv;
-              else s += v[e] * xv;
-            }
-          }
-        }
-        if (mode == 0) unew = (diag == 0.0) ? uk : (bi - s) / diag;
-        else if (mode == 1) unew = (bi - s) / diag;
-        else unew = uk + omega * ((bi - s - s2) / diag - uk);
-        pub[lane] = unew;
+      for (int e = 0; e < MAXE; ++e) pv[e] = pub[sidx[e]];
+      double s = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) {
+        const double t = dep[e] ? v[e] * pv[e] : term[e];
+        s = (kind[e] == 1) ? s + t : s;
+        s2 = (kind[e] == 2) ? s2 + t : s2;
       }
+      double cand;
+      if (mode == 0) cand = (diag == 0.0) ? uk : (bi - s) / diag;
+      else if (mode == 1) cand = (bi - s) / diag;
+      else cand = uk + omega * ((bi - s - s2) / diag - uk);
+      unew = (live && depth == d) ? cand : unew;
+      __syncthreads();       // everybody has read pub of the previous step
+      pub[lane] = unew;      // final once depth <= d; earlier values are never consumed
       __syncthreads();
     }
-    if (row >= 0) u[row] = unew;
+    if (live) u[row] = unew;
     __threadfence_block();
     __syncthreads();
   }
@@ -606,14 +622,13 @@ __global__ __launch_bounds__(BLOCK) void gs_lex_window(
 template <int BLOCK>
 static hipError_t launch_gs_lex_b(const LexDev& S, const double* b, double* u, int mode,
                                   double omega, hipStream_t st) {
-  if (S.width <= 8)
-    hipLaunchKernelGGL((gs_lex_window<BLOCK, 8>), dim3(1), dim3(BLOCK), 0, st, S.n_slots,
-                       S.width, S.row, S.depth, S.win_depth, S.col, S.val, S.src, b, u, mode,
-                       omega);
-  else
-    hipLaunchKernelGGL((gs_lex_window<BLOCK, 16>), dim3(1), dim3(BLOCK), 0, st, S.n_slots,
-                       S.width, S.row, S.depth, S.win_depth, S.col, S.val, S.src, b, u, mode,
-                       omega);
+#define AMG_LEX(M) hipLaunchKernelGGL((gs_lex_window<BLOCK, M>), dim3(1), dim3(BLOCK), 0, st, S.n_slots, \
+                                      S.width, S.row, S.depth, S.win_depth, S.col, S.val, S.src, b, u, mode, omega)
+  if (S.width <= 5) AMG_LEX(5);
+  else if (S.width <= 7) AMG_LEX(7);
+  else if (S.width <= 9) AMG_LEX(9);
+  else AMG_LEX(16);
+#undef AMG_LEX
   return hipGetLastError();
 }
 hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, double omega,
