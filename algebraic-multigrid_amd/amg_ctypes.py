@@ -39,6 +39,16 @@ class Options(C.Structure):
                 ("reserved", C.c_int32 * 3), ("stream", C.c_void_p)]
 
 
+class HaloDesc(C.Structure):
+    _fields_ = [("dst_prev", C.c_void_p), ("src_prev", C.c_void_p), ("bytes_prev", C.c_int64),
+                ("dst_next", C.c_void_p), ("src_next", C.c_void_p), ("bytes_next", C.c_int64),
+                ("data_flag_at_prev", C.c_void_p), ("data_flag_at_next", C.c_void_p),
+                ("my_data_from_prev", C.c_void_p), ("my_data_from_next", C.c_void_p),
+                ("ack_flag_at_prev", C.c_void_p), ("ack_flag_at_next", C.c_void_p),
+                ("my_ack_from_prev", C.c_void_p), ("my_ack_from_next", C.c_void_p),
+                ("epoch", C.c_uint32), ("recv_from_prev", C.c_int32), ("recv_from_next", C.c_int32)]
+
+
 # name -> (restype, argtypes).  Must list EVERY symbol include/amg_hip.h declares
 # (tests/test_cabi_symbols.py checks the header against this table).
 _SIGS = {
@@ -96,6 +106,14 @@ _SIGS = {
     "amg_hip_dev_jacobi_from_zero": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_double, C.c_void_p]),
     "amg_hip_dev_axpy1": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "amg_hip_arena_create": (C.c_int, [C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "amg_hip_arena_destroy": (None, [C.c_void_p]),
+    "amg_hip_arena_base": (C.c_void_p, [C.c_void_p]),
+    "amg_hip_arena_export": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "amg_hip_arena_open_peer": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "amg_hip_arena_close_peer": (C.c_int, [C.c_void_p]),
+    "amg_hip_halo_push_wait": (C.c_int, [C.POINTER(HaloDesc), C.c_void_p]),
+    "amg_hip_halo_ack": (C.c_int, [C.POINTER(HaloDesc), C.c_void_p]),
     "amg_hip_dev_sumsq": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

@@ -1135,6 +1135,103 @@ amg_hip_status amg_hip_spgs_sweep(int32_t dir, int64_t n, const int32_t* colptr,
   return AMG_HIP_OK;
 }
 
+// ---- hipIpc arena + stream-ordered halo exchange ---------------------------------
+struct amg_hip_arena_impl {
+  void* base = nullptr;
+  int64_t bytes = 0;
+  int device = 0;
+};
+
+amg_hip_status amg_hip_arena_create(int64_t bytes, int32_t device, amg_hip_arena** out) {
+  if (!out || bytes <= 0) return fail(AMG_HIP_EINVAL, "bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(AMG_HIP_EHIP, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0) HIP_TRY(hipGetDevice(&device));
+  HIP_TRY(hipSetDevice(device));
+  std::unique_ptr<amg_hip_arena_impl> a(new amg_hip_arena_impl);
+  a->bytes = bytes;
+  a->device = device;
+  HIP_TRY(hipMalloc(&a->base, (size_t)bytes));
+  HIP_TRY(hipMemset(a->base, 0, (size_t)bytes));
+  HIP_TRY(hipDeviceSynchronize());
+  *out = reinterpret_cast<amg_hip_arena*>(a.release());
+  return AMG_HIP_OK;
+}
+void amg_hip_arena_destroy(amg_hip_arena* h) {
+  auto* a = reinterpret_cast<amg_hip_arena_impl*>(h);
+  if (!a) return;
+  if (a->base) {
+    (void)hipSetDevice(a->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(a->base);
+  }
+  delete a;
+}
+void* amg_hip_arena_base(const amg_hip_arena* h) {
+  return h ? reinterpret_cast<const amg_hip_arena_impl*>(h)->base : nullptr;
+}
+amg_hip_status amg_hip_arena_export(const amg_hip_arena* h, uint8_t handle[64]) {
+  auto* a = reinterpret_cast<const amg_hip_arena_impl*>(h);
+  if (!a || !handle) return fail(AMG_HIP_EINVAL, "bad argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  hipIpcMemHandle_t hd;
+  HIP_TRY(hipIpcGetMemHandle(&hd, a->base));
+  std::memcpy(handle, &hd, 64);
+  return AMG_HIP_OK;
+}
+amg_hip_status amg_hip_arena_open_peer(const uint8_t handle[64], void** peer_base) {
+  if (!handle || !peer_base) return fail(AMG_HIP_EINVAL, "bad argument");
+  hipIpcMemHandle_t hd;
+  std::memcpy(&hd, handle, 64);
+  HIP_TRY(hipIpcOpenMemHandle(peer_base, hd, hipIpcMemLazyEnablePeerAccess));
+  return AMG_HIP_OK;
+}
+amg_hip_status amg_hip_arena_close_peer(void* peer_base) {
+  if (!peer_base) return AMG_HIP_OK;
+  HIP_TRY(hipIpcCloseMemHandle(peer_base));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_halo_push_wait(const amg_hip_halo_desc* d, void* stream) {
+  if (!d || d->epoch == 0) return fail(AMG_HIP_EINVAL, "bad halo descriptor");
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t e = d->epoch;
+  const bool to_prev = d->dst_prev && d->bytes_prev > 0, to_next = d->dst_next && d->bytes_next > 0;
+  // 1. my previous message on this channel must have been consumed
+  if (e > 1) {
+    if (to_prev && d->my_ack_from_prev)
+      HIP_TRY(hipStreamWaitValue32(st, d->my_ack_from_prev, e - 1, hipStreamWaitValueGte, 0xffffffffu));
+    if (to_next && d->my_ack_from_next)
+      HIP_TRY(hipStreamWaitValue32(st, d->my_ack_from_next, e - 1, hipStreamWaitValueGte, 0xffffffffu));
+  }
+  // 2. push + publish
+  if (to_prev) {
+    HIP_TRY(hipMemcpyAsync(d->dst_prev, d->src_prev, (size_t)d->bytes_prev, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamWriteValue32(st, d->data_flag_at_prev, e, 0));
+  }
+  if (to_next) {
+    HIP_TRY(hipMemcpyAsync(d->dst_next, d->src_next, (size_t)d->bytes_next, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamWriteValue32(st, d->data_flag_at_next, e, 0));
+  }
+  // 3. wait for the neighbours' data of this epoch
+  if (d->recv_from_prev)
+    HIP_TRY(hipStreamWaitValue32(st, d->my_data_from_prev, e, hipStreamWaitValueGte, 0xffffffffu));
+  if (d->recv_from_next)
+    HIP_TRY(hipStreamWaitValue32(st, d->my_data_from_next, e, hipStreamWaitValueGte, 0xffffffffu));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_halo_ack(const amg_hip_halo_desc* d, void* stream) {
+  if (!d || d->epoch == 0) return fail(AMG_HIP_EINVAL, "bad halo descriptor");
+  hipStream_t st = (hipStream_t)stream;
+  if (d->recv_from_prev && d->ack_flag_at_prev)
+    HIP_TRY(hipStreamWriteValue32(st, d->ack_flag_at_prev, d->epoch, 0));
+  if (d->recv_from_next && d->ack_flag_at_next)
+    HIP_TRY(hipStreamWriteValue32(st, d->ack_flag_at_next, d->epoch, 0));
+  return AMG_HIP_OK;
+}
+
 // ---- generators -----------------------------------------------------------------
 int64_t amg_hip_laplacian(int32_t dim, int64_t n, int32_t* colptr, int32_t* rowind,
                           double* val) {

@@ -212,6 +212,22 @@ class _HipTail:
         return self.mg.rss()
 
 
+class IpcUnavailable(RuntimeError):
+    """Raised on EVERY rank when the hipIpc halo path cannot be set up on some rank."""
+
+
+class _DevArray:
+    """__cuda_array_interface__ view of raw device memory (arena slices)."""
+
+    def __init__(self, ptr, n, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def _align(x, a=256):
+    return (x + a - 1) // a * a
+
+
 # ------------------------------------------------------------------- driver ----
 class DistLevel:
     pass
@@ -221,13 +237,18 @@ class DistributedVcycle:
     """multigrid.hpp:263-305 over row-block shards (true Jacobi smoother)."""
 
     def __init__(self, hierarchy, b, backend, rank, world, omega=0.6, sweeps=2,
-                 dist_min_rows=6000000, group=None, host_staged=False):
+                 dist_min_rows=6000000, group=None, host_staged=False, comm="p2p"):
         """hierarchy: object with n_levels, get_n_dofs(l), get_coefficient_matrix(l)
         -> CSC (colptr, rowind, val) of the (symmetric) level matrix.
         host_staged: exchange through host buffers (a process group whose backend
         cannot move device tensors, e.g. gloo with a GPU compute backend)."""
         self.be, self.rank, self.world, self.group = backend, rank, world, group
         self.host_staged = bool(host_staged)
+        # comm: "p2p" = torch.distributed isend/irecv (RCCL); "ipc" = direct pushes into
+        # the neighbours' hipIpc-mapped halo slots with stream-ordered epoch flags
+        self.comm = comm
+        self.arena = None
+        self._peer_bases = {}
         self.omega, self.sweeps = float(omega), int(sweeps)
         L = hierarchy.n_levels
         self.n_levels = L
@@ -270,10 +291,8 @@ class DistributedVcycle:
             dg[rows_l[on_d]] = D.A.val[on_d]
             D.diag = backend.from_numpy(dg)
             n_ext = D.A.halo_lo + (e - s) + D.A.halo_hi
-            D.u = backend.vec(n_ext)
-            D.u2 = backend.vec(n_ext)
+            D.n_ext = n_ext
             D.f = backend.vec(e - s)
-            D.r = backend.vec(e - s + 2)            # residual with a width-1 halo each side
             D.tmp = backend.vec(e - s)
             cs, ce = bounds[l + 1][rank], bounds[l + 1][rank + 1]
             D.cs, D.ce = cs, ce
@@ -281,8 +300,16 @@ class DistributedVcycle:
             D.R = backend.matrix(rp, c, vv)
             rp, c, vv = linear_P_rows(s, e, sizes[l + 1], cs)
             D.P = backend.matrix(rp, c, vv)
-            D.uH = backend.vec(ce - cs + 2)         # coarse correction with width-1 halos
             self.lv.append(D)
+        # exchangeable vectors: u, u2 (halo-extended), r and uH (width-1 halos)
+        if self.comm == "ipc" and self.n_dist:
+            self._setup_ipc()
+        else:
+            for D in self.lv:
+                D.u = backend.vec(D.n_ext)
+                D.u2 = backend.vec(D.n_ext)
+                D.r = backend.vec(D.e - D.s + 2)
+                D.uH = backend.vec(D.ce - D.cs + 2)
         # halo widths of every rank, so senders know how much a neighbour wants
         if self.n_dist:
             mine = torch.tensor([[D.A.halo_lo, D.A.halo_hi] for D in self.lv], dtype=torch.int64,
@@ -311,6 +338,145 @@ class DistributedVcycle:
             D0.f.copy_(backend.from_numpy(np.asarray(b[D0.s:D0.e], dtype=np.float64)))
         else:  # nothing is big enough to shard: every rank runs the whole cycle
             self.tail_f.copy_(backend.from_numpy(np.asarray(b, dtype=np.float64)))
+
+    # ---- hipIpc mode: arena, peers, descriptors ----
+    def _setup_ipc(self):
+        amg, lib = self.be.amg, self.be.lib
+        import ctypes as C
+        dev = self.be.device
+        # layout of my arena: per level [u | u2 | r | uH | 16 flag words]
+        table, off = [], 0
+        for D in self.lv:
+            n, nH = D.e - D.s, D.ce - D.cs
+            row = []
+            for cnt in (D.n_ext, D.n_ext, n + 2, nH + 2):
+                row.append(off)
+                off = _align(off + 8 * max(cnt, 1))
+            row.append(off)                      # flags
+            off = _align(off + 64)
+            row += [D.A.halo_lo, D.A.halo_hi, n, nH]
+            table.append(row)
+        cdev = "cpu" if self.host_staged else dev
+
+        def all_ok(ok, what):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            if int(t.item()) == 0:
+                self._ipc_cleanup()
+                raise IpcUnavailable(what)
+
+        h = C.c_void_p()
+        hb = C.create_string_buffer(64)
+        ok = (lib.amg_hip_arena_create(max(off, 256), dev.index, C.byref(h)) == 0)
+        if ok:
+            self.arena = h
+            ok = (lib.amg_hip_arena_export(h, hb) == 0)
+        all_ok(ok, "hipIpc arena could not be created / exported on some rank")
+        base = lib.amg_hip_arena_base(h)
+        self._base = base
+        for D, row in zip(self.lv, table):
+            n, nH = D.e - D.s, D.ce - D.cs
+            mk = lambda o, cnt: torch.as_tensor(_DevArray(base + o, cnt), device=dev)
+            D.u, D.u2 = mk(row[0], D.n_ext), mk(row[1], D.n_ext)
+            D.r, D.uH = mk(row[2], n + 2), mk(row[3], nH + 2)
+            D.chan = {D.u.data_ptr(): 0, D.u2.data_ptr(): 1, D.r.data_ptr(): 2, D.uH.data_ptr(): 3}
+            D.epoch = [0, 0, 0, 0]
+            D.desc = [None] * 4
+        # exchange handles and layout tables
+        mine = torch.tensor(list(hb.raw), dtype=torch.uint8, device=cdev)
+        handles = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(handles, mine, group=self.group)
+        tab = torch.tensor(table, dtype=torch.int64, device=cdev)
+        tabs = [torch.zeros_like(tab) for _ in range(self.world)]
+        dist.all_gather(tabs, tab, group=self.group)
+        self._tabs = [t.cpu().tolist() for t in tabs]
+        ok = True
+        for g in (self.rank - 1, self.rank + 1):
+            if 0 <= g < self.world:
+                pb = C.c_void_p()
+                raw = bytes(handles[g].cpu().tolist())
+                if lib.amg_hip_arena_open_peer(raw, C.byref(pb)) == 0:
+                    self._peer_bases[g] = pb.value
+                else:
+                    ok = False
+        all_ok(ok, "a neighbour's hipIpc arena could not be mapped on some rank")
+
+    def _ipc_cleanup(self):
+        for pb in self._peer_bases.values():
+            self.be.lib.amg_hip_arena_close_peer(pb)
+        self._peer_bases = {}
+        for D in self.lv:
+            D.u = D.u2 = D.r = D.uH = None
+        if self.arena is not None:
+            self.be.lib.amg_hip_arena_destroy(self.arena)
+            self.arena = None
+
+    def _ipc_desc(self, l, chan, n_owned, lo, hi, send_prev, send_next):
+        """Static part of the descriptor of channel `chan` on level l."""
+        amg = self.be.amg
+        D = self.lv[l]
+        r, w = self.rank, self.world
+        me = self._tabs[r][l]
+        d = amg.HaloDesc()
+        fl = self._base + me[4] + 16 * chan          # my 4 flag words of this channel
+        d.my_data_from_prev, d.my_data_from_next = fl, fl + 4
+        d.my_ack_from_prev, d.my_ack_from_next = fl + 8, fl + 12
+        mybuf = self._base + me[chan]
+        d.recv_from_prev = int(r > 0 and lo > 0)
+        d.recv_from_next = int(r < w - 1 and hi > 0)
+        if r > 0:
+            pt = self._tabs[r - 1][l]
+            pb = self._peer_bases[r - 1]
+            pfl = pb + pt[4] + 16 * chan
+            if chan < 2:
+                p_lo, p_n = pt[5], pt[7]
+            else:
+                p_lo, p_n = 1, (pt[7] if chan == 2 else pt[8])
+            if send_prev > 0:
+                d.src_prev = mybuf + 8 * lo
+                d.dst_prev = pb + pt[chan] + 8 * (p_lo + p_n)   # its upper halo
+                d.bytes_prev = 8 * send_prev
+            d.data_flag_at_prev = pfl + 4        # its "data from next"
+            d.ack_flag_at_prev = pfl + 12        # its "ack from next"
+        if r < w - 1:
+            nt = self._tabs[r + 1][l]
+            nb = self._peer_bases[r + 1]
+            nfl = nb + nt[4] + 16 * chan
+            if send_next > 0:
+                d.src_next = mybuf + 8 * (lo + n_owned - send_next)
+                d.dst_next = nb + nt[chan]                       # its lower halo starts the vector
+                d.bytes_next = 8 * send_next
+            d.data_flag_at_next = nfl            # its "data from prev"
+            d.ack_flag_at_next = nfl + 8         # its "ack from prev"
+        return d
+
+    def _exchange_ipc(self, l, vec, n_owned, lo, hi, send_prev, send_next):
+        import ctypes as C
+        D = self.lv[l]
+        chan = D.chan[vec.data_ptr()]
+        if D.desc[chan] is None:
+            D.desc[chan] = self._ipc_desc(l, chan, n_owned, lo, hi, send_prev, send_next)
+        d = D.desc[chan]
+        D.epoch[chan] += 1
+        d.epoch = D.epoch[chan]
+        self.be._chk(self.be.lib.amg_hip_halo_push_wait(C.byref(d), self.be.stream()))
+
+    def _consumed(self, l, vec):
+        """The kernel that read vec's halos has been enqueued: acknowledge."""
+        if self.comm != "ipc":
+            return
+        import ctypes as C
+        D = self.lv[l]
+        d = D.desc[D.chan[vec.data_ptr()]]
+        if d is not None:
+            self.be._chk(self.be.lib.amg_hip_halo_ack(C.byref(d), self.be.stream()))
+
+    def close(self):
+        if self.arena is not None:
+            self.be.sync()
+            dist.barrier(group=self.group)   # nobody is still pushing into anybody's arena
+            self._ipc_cleanup()
+            dist.barrier(group=self.group)
 
     # ---- halo exchange of an extended vector [lo | owned | hi] ----
     def _exchange(self, vec, n_owned, lo, hi, send_prev, send_next):
@@ -366,10 +532,16 @@ class DistributedVcycle:
         r = self.rank
         send_prev = h[r - 1][1] if r > 0 else 0               # what rank-1 wants above its block
         send_next = h[r + 1][0] if r < self.world - 1 else 0  # what rank+1 wants below its block
-        self._exchange(vec, D.e - D.s, D.A.halo_lo, D.A.halo_hi, send_prev, send_next)
+        if self.comm == "ipc":
+            self._exchange_ipc(l, vec, D.e - D.s, D.A.halo_lo, D.A.halo_hi, send_prev, send_next)
+        else:
+            self._exchange(vec, D.e - D.s, D.A.halo_lo, D.A.halo_hi, send_prev, send_next)
 
-    def _exchange_1(self, vec, n_owned):
-        self._exchange(vec, n_owned, 1, 1, 1, 1)
+    def _exchange_1(self, l, vec, n_owned):
+        if self.comm == "ipc":
+            self._exchange_ipc(l, vec, n_owned, 1, 1, 1, 1)
+        else:
+            self._exchange(vec, n_owned, 1, 1, 1, 1)
 
     # ---- smoother: `sweeps` two-buffer Jacobi passes on level l ----
     def _smooth(self, l, from_zero=False):
@@ -384,6 +556,7 @@ class DistributedVcycle:
                 continue
             self._exchange_u(l, D.u)
             self.be.jacobi(D.mat, D.u, D.f, D.u2[lo:lo + n], self.omega, D.A.diag_shift)
+            self._consumed(l, D.u)
             D.u, D.u2 = D.u2, D.u
 
     def vcycle(self):
@@ -395,7 +568,8 @@ class DistributedVcycle:
             self._smooth(l, from_zero=(l >= 1 and self.sweeps >= 1))  # :268
             self._exchange_u(l, D.u)
             be.residual(D.mat, D.u, D.f, D.r[1:1 + n])       # :272-274
-            self._exchange_1(D.r, n)
+            self._consumed(l, D.u)
+            self._exchange_1(l, D.r, n)
             nH = D.ce - D.cs
             if l + 1 < nd:                                    # :278, :281-282
                 C = self.lv[l + 1]
@@ -404,6 +578,7 @@ class DistributedVcycle:
                 be.spmv(D.R, D.r, C.f)
             else:
                 be.spmv(D.R, D.r, self.gather_in[:nH])
+            self._consumed(l, D.r)
         # ---- agglomerated levels (coarse solve included), redundantly on every rank ----
         if nd == 0:
             self.tail.cycle(self.tail_f, self.tail_u, zero_guess=False)
@@ -423,12 +598,16 @@ class DistributedVcycle:
                 C = self.lv[l + 1]
                 clo = C.A.halo_lo
                 D.uH[1:1 + nH].copy_(C.u[clo:clo + nH])
-                self._exchange_1(D.uH, nH)
+                self._exchange_1(l, D.uH, nH)
+                exchanged = True
             else:  # every rank holds the whole level: halo entries are local reads
                 g0 = max(D.cs - 1, 0)
                 g1 = min(D.ce + 1, self.tail_n)
                 D.uH[(g0 - (D.cs - 1)):(g1 - (D.cs - 1))].copy_(self.tail_u[g0:g1])
+                exchanged = False
             be.spmv(D.P, D.uH, D.tmp)                         # :294-296
+            if exchanged:
+                self._consumed(l, D.uH)
             be.add_(D.u[lo:lo + n], D.tmp)
             self._smooth(l)                                   # :300
 
@@ -441,6 +620,7 @@ class DistributedVcycle:
         n = D.e - D.s
         self._exchange_u(0, D.u)
         self.be.residual(D.mat, D.u, D.f, D.r[1:1 + n])
+        self._consumed(0, D.u)
         part = self._all_reduce_sum(self.be.sumsq(D.r[1:1 + n]).to(torch.float64))
         return float(part.item())
 
@@ -488,27 +668,53 @@ def bench(args):
     hier = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_JACOBI,
                          smoother_iters=args.sweeps, omega=args.omega, host_only=True)
     del colptr, rowind, val
+    def timed(dv):
+        for _ in range(args.warmup):
+            dv.vcycle()
+        r0 = dv.rss()
+        be.sync()
+        dist.barrier()
+        be.sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            dv.vcycle()
+        be.sync()
+        dist.barrier()
+        be.sync()
+        el = torch.tensor([time.perf_counter() - t1], dtype=torch.float64,
+                          device="cpu" if rehearsal else be.device)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), r0, dv.rss()
+
+    # halo exchange through torch.distributed isend/irecv (RCCL): always available
     dv = DistributedVcycle(hier, b, be, rank, world, omega=args.omega, sweeps=args.sweeps,
-                           dist_min_rows=args.dist_min_rows, host_staged=rehearsal)
+                           dist_min_rows=args.dist_min_rows, host_staged=rehearsal, comm="p2p")
+    results = {"p2p": timed(dv)}
+    # direct pushes over hipIpc (xGMI): used when it sets up on every rank AND reproduces
+    # the p2p result bit for bit (same cycles from the same start => identical rss)
+    ipc_note = "not tried"
+    if args.comm in ("auto", "ipc") and dv.n_dist:
+        try:
+            dv_ipc = DistributedVcycle(hier, b, be, rank, world, omega=args.omega,
+                                       sweeps=args.sweeps, dist_min_rows=args.dist_min_rows,
+                                       host_staged=rehearsal, comm="ipc")
+            res = timed(dv_ipc)
+            same = (res[1] == results["p2p"][1]) and (res[2] == results["p2p"][2])
+            flag = torch.tensor([1 if same else 0], dtype=torch.int32,
+                                device="cpu" if rehearsal else be.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                results["ipc"] = res
+                ipc_note = "ok"
+            else:
+                ipc_note = "ran but did not reproduce the p2p result; discarded"
+            dv_ipc.close()
+        except IpcUnavailable as ex:
+            ipc_note = f"unavailable: {ex}"
     hier.close()
     setup_s = time.time() - t0
-    for _ in range(args.warmup):
-        dv.vcycle()
-    rss0 = dv.rss()
-    be.sync()
-    dist.barrier()
-    be.sync()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        dv.vcycle()
-    be.sync()
-    dist.barrier()
-    be.sync()
-    dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64,
-                      device="cpu" if rehearsal else be.device)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt.item())
-    rss = dv.rss()
+    best = min(results, key=lambda k: results[k][0])
+    dt, rss0, rss = results[best]
     # dominant kernel: this rank's level-0 Jacobi sweep (HIP events on torch's stream)
     D = dv.lv[0]
     lo, n = D.A.halo_lo, D.e - D.s
@@ -540,6 +746,8 @@ def bench(args):
                              f"rest agglomerated), fp64"),
                 "n": args.n, "levels": L, "distributed_levels": dv.n_dist, "rehearsal": rehearsal,
                 "dist_min_rows": args.dist_min_rows, "setup_seconds": setup_s,
+                "halo_exchange": best, "ipc": ipc_note,
+                "vcycles_per_sec_by_exchange": {k: args.steps / v[0] for k, v in results.items()},
                 "rss_after_warmup": rss0, "rss_after_steps": rss,
             },
             "roofline": {

@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=2048, help="grid of the CPU baseline sample")
     ap.add_argument("--cpu-cycles", type=int, default=5)
     ap.add_argument("--profile-launches", type=int, default=40)
+    ap.add_argument("--comm", choices=["auto", "p2p", "ipc"], default="auto",
+                    help="multi-GPU halo exchange: torch.distributed isend/irecv (RCCL) or direct "
+                         "hipIpc pushes; auto = time both, keep the faster one that matches")
     ap.add_argument("--dist-min-rows", type=int, default=6000000,
                     help="multi-GPU: levels with fewer rows (in total) run redundantly on every rank")
     args = ap.parse_args()

@@ -300,6 +300,48 @@ amg_hip_status amg_hip_dev_axpy1(int64_t n, const double* x, double* y, void* st
 amg_hip_status amg_hip_dev_sumsq(int64_t n, const double* r, double* out,
                                  double* scratch, void* stream);
 
+/* ---- peer-to-peer halo exchange over hipIpc (xGMI inside a node) --------------
+ * The multi-GPU driver's neighbour exchange without a collective: every rank
+ * allocates its exchangeable vectors inside one arena, exports it with hipIpc,
+ * maps the arenas of rank-1 / rank+1, and then pushes its boundary unknowns
+ * straight into the neighbour's halo slots with stream-ordered copies; arrival
+ * and consumption are signalled with 32-bit epoch words in the arenas
+ * (hipStreamWriteValue32 / hipStreamWaitValue32: no host synchronisation, no
+ * spinning kernel).  Bootstrap (exchanging the 64-byte handles and the layout
+ * tables) is done by the host through torch.distributed.                      */
+typedef struct amg_hip_arena amg_hip_arena;
+amg_hip_status amg_hip_arena_create(int64_t bytes, int32_t device, amg_hip_arena** out);
+void amg_hip_arena_destroy(amg_hip_arena* a);
+void* amg_hip_arena_base(const amg_hip_arena* a);
+/* 64-byte hipIpcMemHandle_t of the arena */
+amg_hip_status amg_hip_arena_export(const amg_hip_arena* a, uint8_t handle[64]);
+amg_hip_status amg_hip_arena_open_peer(const uint8_t handle[64], void** peer_base);
+amg_hip_status amg_hip_arena_close_peer(void* peer_base);
+
+/* One exchange with both neighbours.  Any side may be absent (NULL / 0).
+ * push_wait:  wait until the neighbours acknowledged epoch-1 (my previous data
+ * has been consumed) -> copy my boundary into their halo slots -> publish
+ * `epoch` in their arenas -> wait until their data of `epoch` has landed in
+ * mine.  ack: tell the neighbours that the halo data of `epoch` has been
+ * consumed (call it after the kernel that read the halos).                    */
+typedef struct {
+  void* dst_prev; const void* src_prev; int64_t bytes_prev;  /* my first rows -> rank-1's upper halo */
+  void* dst_next; const void* src_next; int64_t bytes_next;  /* my last rows  -> rank+1's lower halo */
+  uint32_t* data_flag_at_prev;  /* word in rank-1's arena: "data from my next has landed" */
+  uint32_t* data_flag_at_next;  /* word in rank+1's arena: "data from my prev has landed" */
+  uint32_t* my_data_from_prev;  /* words in MY arena the neighbours publish into          */
+  uint32_t* my_data_from_next;
+  uint32_t* ack_flag_at_prev;   /* word in rank-1's arena: "my next consumed my data"     */
+  uint32_t* ack_flag_at_next;
+  uint32_t* my_ack_from_prev;   /* words in MY arena: the neighbour consumed what I sent  */
+  uint32_t* my_ack_from_next;
+  uint32_t epoch;               /* 1, 2, 3, ... per channel                               */
+  int32_t recv_from_prev;       /* 1 when rank-1 sends me data on this channel            */
+  int32_t recv_from_next;
+} amg_hip_halo_desc;
+amg_hip_status amg_hip_halo_push_wait(const amg_hip_halo_desc* d, void* stream);
+amg_hip_status amg_hip_halo_ack(const amg_hip_halo_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

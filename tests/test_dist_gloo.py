@@ -39,7 +39,7 @@ class _OracleHierarchy:
 
 
 def _worker(rank, world, port, n, L, cycles, agg, sweeps, omega, out_dir, use_product_hierarchy,
-            gpu=False):
+            gpu=False, comm="p2p"):
     for p in (ROOT, os.path.join(ROOT, "algebraic-multigrid_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -60,7 +60,7 @@ def _worker(rank, world, port, n, L, cycles, agg, sweeps, omega, out_dir, use_pr
     else:
         be = CpuBackend(O)
     dv = dist_vcycle.DistributedVcycle(hier, b, be, rank, world, omega=omega,
-                                       sweeps=sweeps, dist_min_rows=agg, host_staged=gpu)
+                                       sweeps=sweeps, dist_min_rows=agg, host_staged=gpu, comm=comm)
     rss = []
     for _ in range(cycles):
         dv.vcycle()
@@ -68,14 +68,17 @@ def _worker(rank, world, port, n, L, cycles, agg, sweeps, omega, out_dir, use_pr
     u = dv.gather_solution()
     if rank == 0:
         np.savez(os.path.join(out_dir, "out.npz"), u=u, rss=np.array(rss), n_dist=dv.n_dist)
+    if hasattr(dv, "close"):
+        dv.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(tmp_path, world, n, L, cycles, agg, sweeps=2, omega=0.6, product_hier=True, gpu=False):
+def _run(tmp_path, world, n, L, cycles, agg, sweeps=2, omega=0.6, product_hier=True, gpu=False,
+         comm="p2p"):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, L, cycles, agg, sweeps, omega, str(tmp_path), product_hier, gpu),
-             nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, L, cycles, agg, sweeps, omega, str(tmp_path), product_hier,
+                            gpu, comm), nprocs=world, join=True)
     return np.load(os.path.join(str(tmp_path), "out.npz"))
 
 
@@ -130,6 +133,23 @@ def test_partition_helpers():
                 for j in (b1[g], b1[g + 1] - 1):
                     if b1[g] < b1[g + 1]:
                         assert b0[g] <= 2 * j + 1 < b0[g + 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_vcycle_hipipc_halo_exchange_on_one_gpu(tmp_path, oracle, world):
+    """Halo exchange by direct pushes into the neighbours' hipIpc-mapped arenas with
+    stream-ordered epoch flags (amg_hip_halo_push_wait / _ack): `world` processes on
+    GPU 0; gloo only bootstraps (handles, layout tables) and carries the all-gather."""
+    n, L, cycles = 96, 7, 4
+    got = _run(tmp_path, world, n, L, cycles, agg=900, gpu=True, comm="ipc")
+    assert int(got["n_dist"]) >= 3
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
+    for c in range(cycles):
+        ref.vcycle()
+        assert abs(got["rss"][c] - ref.rss()) <= 1e-12 * ref.rss()
+    assert np.array_equal(got["u"], ref.get_vec(0, "u"))
 
 
 @pytest.mark.gpu
