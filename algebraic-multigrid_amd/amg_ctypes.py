@@ -49,6 +49,23 @@ class HaloDesc(C.Structure):
                 ("epoch", C.c_uint32), ("recv_from_prev", C.c_int32), ("recv_from_next", C.c_int32)]
 
 
+class HaloKDesc(C.Structure):
+    _fields_ = [("dst_prev", C.c_void_p), ("src_prev", C.c_void_p), ("cnt_prev", C.c_int64),
+                ("dst_next", C.c_void_p), ("src_next", C.c_void_p), ("cnt_next", C.c_int64),
+                ("my_free_from_prev", C.c_void_p), ("my_free_from_next", C.c_void_p),
+                ("data_at_prev", C.c_void_p), ("data_at_next", C.c_void_p),
+                ("my_data_from_prev", C.c_void_p), ("my_data_from_next", C.c_void_p),
+                ("recv_prev", C.c_int32), ("recv_next", C.c_int32), ("timeout", C.c_void_p)]
+
+
+class GatherKDesc(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("src", C.c_void_p),
+                ("cnt", C.c_int64), ("off", C.c_int64), ("dst", C.c_void_p * 16),
+                ("data_at", C.c_void_p * 16), ("free_at", C.c_void_p * 16),
+                ("my_data_from", C.c_void_p), ("my_free_from", C.c_void_p),
+                ("timeout", C.c_void_p)]
+
+
 # name -> (restype, argtypes).  Must list EVERY symbol include/amg_hip.h declares
 # (tests/test_cabi_symbols.py checks the header against this table).
 _SIGS = {
@@ -114,6 +131,15 @@ _SIGS = {
     "amg_hip_arena_close_peer": (C.c_int, [C.c_void_p]),
     "amg_hip_halo_push_wait": (C.c_int, [C.POINTER(HaloDesc), C.c_void_p]),
     "amg_hip_halo_ack": (C.c_int, [C.POINTER(HaloDesc), C.c_void_p]),
+    "amg_hip_halo_exchange_kernel": (C.c_int, [C.POINTER(HaloKDesc), C.c_void_p]),
+    "amg_hip_halo_ack_kernel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "amg_hip_gather_kernel": (C.c_int, [C.POINTER(GatherKDesc), C.c_void_p]),
+    "amg_hip_gather_ack_kernel": (C.c_int, [C.POINTER(GatherKDesc), C.c_void_p]),
+    "amg_hip_fill_u32": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p]),
+    "amg_hip_capture_begin": (C.c_int, [C.c_void_p]),
+    "amg_hip_capture_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "amg_hip_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "amg_hip_graph_destroy": (None, [C.c_void_p]),
     "amg_hip_dev_sumsq": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

@@ -643,6 +643,113 @@ hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, 
   return hipErrorInvalidValue;
 }
 
+// ------------------------------------------------------- K-Halo (in-graph comm) ---
+// Neighbour exchange as ONE graph-capturable kernel: the host-driven version
+// (hipMemcpyAsync + hipStreamWrite/WaitValue32, solver.cpp) costs ~3 us of host
+// time per stream operation and those operations cannot be captured in a hipGraph.
+// Protocol per channel and direction, words in the RECEIVER's arena, values 0/1:
+//   DATA  set to 1 by the sender after its boundary values landed in the
+//         receiver's halo slots; reset to 0 by the receiver when it has seen it;
+//   FREE  set to 1 by the receiver (halo_ack_kernel) once the kernel that read the
+//         halo is done; reset to 0 by the sender before it overwrites the slots.
+// One workgroup: lane 0 waits for FREE, all lanes copy (stores to the peer's
+// hipIpc-mapped memory), system fence, lane 0 publishes DATA and waits for its
+// own.  All flag accesses are system-scope atomics; every spin is bounded
+// (~2 s of wall clock) and reports through `timeout`.
+__device__ __forceinline__ bool spin_until_one(uint32_t* w, uint32_t* timeout) {
+  const unsigned long long t0 = wall_clock64();
+  while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 1u) {
+    if (wall_clock64() - t0 > 200000000ull) {  // 100 MHz constant clock
+      __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return true;
+}
+
+__global__ __launch_bounds__(256) void halo_exchange_kernel(HaloArgs a) {
+  const int t = threadIdx.x;
+  if (t == 0) {
+    if (a.cnt_prev > 0) spin_until_one(a.my_free_from_prev, a.timeout);
+    if (a.cnt_next > 0) spin_until_one(a.my_free_from_next, a.timeout);
+  }
+  __syncthreads();
+  for (int64_t i = t; i < a.cnt_prev; i += 256)
+    __builtin_nontemporal_store(a.src_prev[i], a.dst_prev + i);
+  for (int64_t i = t; i < a.cnt_next; i += 256)
+    __builtin_nontemporal_store(a.src_next[i], a.dst_next + i);
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) {
+    if (a.cnt_prev > 0)
+      __hip_atomic_store(a.data_at_prev, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.cnt_next > 0)
+      __hip_atomic_store(a.data_at_next, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.recv_prev) spin_until_one(a.my_data_from_prev, a.timeout);
+    if (a.recv_next) spin_until_one(a.my_data_from_next, a.timeout);
+    __threadfence_system();
+  }
+}
+__global__ void halo_ack_kernel(uint32_t* free_at_prev, uint32_t* free_at_next) {
+  if (threadIdx.x == 0) {
+    if (free_at_prev) __hip_atomic_store(free_at_prev, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (free_at_next) __hip_atomic_store(free_at_next, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+hipError_t launch_halo_exchange(const HaloArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(halo_exchange_kernel, dim3(1), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_halo_ack(uint32_t* free_at_prev, uint32_t* free_at_next, hipStream_t st) {
+  if (!free_at_prev && !free_at_next) return hipSuccess;
+  hipLaunchKernelGGL(halo_ack_kernel, dim3(1), dim3(64), 0, st, free_at_prev, free_at_next);
+  return hipGetLastError();
+}
+
+// All-gather of the agglomeration level's right-hand side by direct pushes:
+// rank r copies its slice into every rank's full vector at offset `off` (its own
+// included).  k1: wait until every destination released the slot (FREE); k2: copy;
+// k3: publish DATA everywhere and wait for everybody's DATA.
+__global__ void gather_wait_free_kernel(GatherArgs a) {
+  const int g = threadIdx.x;
+  if (g < a.world && g != a.rank) spin_until_one(a.my_free_from + g, a.timeout);
+}
+__global__ __launch_bounds__(256) void gather_copy_kernel(GatherArgs a) {
+  const int g = blockIdx.y;
+  double* dst = a.dst[g] + a.off;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.cnt; i += (int64_t)gridDim.x * 256)
+    dst[i] = a.src[i];
+  __threadfence_system();
+}
+__global__ void gather_publish_wait_kernel(GatherArgs a) {
+  const int g = threadIdx.x;
+  if (g < a.world && g != a.rank) {
+    __hip_atomic_store(a.data_at[g], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    spin_until_one(a.my_data_from + g, a.timeout);
+    __threadfence_system();
+  }
+}
+__global__ void gather_ack_kernel(GatherArgs a) {
+  const int g = threadIdx.x;
+  if (g < a.world && g != a.rank)
+    __hip_atomic_store(a.free_at[g], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_gather(const GatherArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(gather_wait_free_kernel, dim3(1), dim3(64), 0, st, a);
+  int64_t gx = (a.cnt + 255) / 256;
+  if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(gather_copy_kernel, dim3((unsigned)gx, (unsigned)a.world), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(gather_publish_wait_kernel, dim3(1), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_gather_ack(const GatherArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(gather_ack_kernel, dim3(1), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ K-Band ---
 // x = A^-1 f with A = L D L^T banded (half-bandwidth w <= 63), ONE wave -- the
 // substitution is a serial chain, so the design goal is the fewest instructions

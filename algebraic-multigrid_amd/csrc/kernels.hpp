@@ -55,6 +55,33 @@ hipError_t launch_add_inplace(int64_t n, const double* x, double* y, hipStream_t
 hipError_t launch_sum(int64_t n, const double* x, double* out, double* scratch, int square,
                       hipStream_t st);
 
+// In-graph neighbour exchange (K-Halo).  All pointers are device pointers; *_at_*
+// and dst_* point into a neighbour's hipIpc-mapped arena.
+struct HaloArgs {
+  double* dst_prev; const double* src_prev; int64_t cnt_prev;
+  double* dst_next; const double* src_next; int64_t cnt_next;
+  uint32_t* my_free_from_prev; uint32_t* my_free_from_next;
+  uint32_t* data_at_prev; uint32_t* data_at_next;
+  uint32_t* my_data_from_prev; uint32_t* my_data_from_next;
+  int32_t recv_prev, recv_next;
+  uint32_t* timeout;
+};
+hipError_t launch_halo_exchange(const HaloArgs& a, hipStream_t st);
+hipError_t launch_halo_ack(uint32_t* free_at_prev, uint32_t* free_at_next, hipStream_t st);
+constexpr int GATHER_MAX_RANKS = 16;
+struct GatherArgs {
+  int32_t rank, world;
+  const double* src; int64_t cnt, off;
+  double* dst[GATHER_MAX_RANKS];          // every rank's full vector (own included)
+  uint32_t* data_at[GATHER_MAX_RANKS];    // word [me] in rank g's DATA block
+  uint32_t* free_at[GATHER_MAX_RANKS];    // word [me] in rank g's FREE block
+  uint32_t* my_data_from;                 // my DATA block, one word per source rank
+  uint32_t* my_free_from;                 // my FREE block, one word per destination rank
+  uint32_t* timeout;
+};
+hipError_t launch_gather(const GatherArgs& a, hipStream_t st);
+hipError_t launch_gather_ack(const GatherArgs& a, hipStream_t st);
+
 struct LexDev {  // device copy of a LexSchedule
   int32_t block = 0, width = 0;
   int64_t n_slots = 0;

@@ -1232,6 +1232,64 @@ amg_hip_status amg_hip_halo_ack(const amg_hip_halo_desc* d, void* stream) {
   return AMG_HIP_OK;
 }
 
+amg_hip_status amg_hip_halo_exchange_kernel(const amg_hip_halo_kdesc* d, void* stream) {
+  if (!d || !d->timeout) return fail(AMG_HIP_EINVAL, "bad halo descriptor");
+  static_assert(sizeof(amg_hip_halo_kdesc) == sizeof(HaloArgs), "layout");
+  HaloArgs a;
+  std::memcpy(&a, d, sizeof(a));
+  HIP_TRY(launch_halo_exchange(a, (hipStream_t)stream));
+  return AMG_HIP_OK;
+}
+amg_hip_status amg_hip_halo_ack_kernel(uint32_t* free_at_prev, uint32_t* free_at_next,
+                                       void* stream) {
+  HIP_TRY(launch_halo_ack(free_at_prev, free_at_next, (hipStream_t)stream));
+  return AMG_HIP_OK;
+}
+amg_hip_status amg_hip_gather_kernel(const amg_hip_gather_kdesc* d, void* stream) {
+  if (!d || d->world < 1 || d->world > GATHER_MAX_RANKS) return fail(AMG_HIP_EINVAL, "bad gather descriptor");
+  static_assert(sizeof(amg_hip_gather_kdesc) == sizeof(GatherArgs), "layout");
+  GatherArgs a;
+  std::memcpy(&a, d, sizeof(a));
+  HIP_TRY(launch_gather(a, (hipStream_t)stream));
+  return AMG_HIP_OK;
+}
+amg_hip_status amg_hip_gather_ack_kernel(const amg_hip_gather_kdesc* d, void* stream) {
+  if (!d || d->world < 1 || d->world > GATHER_MAX_RANKS) return fail(AMG_HIP_EINVAL, "bad gather descriptor");
+  GatherArgs a;
+  std::memcpy(&a, d, sizeof(a));
+  HIP_TRY(launch_gather_ack(a, (hipStream_t)stream));
+  return AMG_HIP_OK;
+}
+amg_hip_status amg_hip_fill_u32(uint32_t* dev_ptr, int64_t count, uint32_t value, void* stream) {
+  if (!dev_ptr || count < 0) return fail(AMG_HIP_EINVAL, "bad argument");
+  HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)dev_ptr, (int)value, (size_t)count, (hipStream_t)stream));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_capture_begin(void* stream) {
+  HIP_TRY(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed));
+  return AMG_HIP_OK;
+}
+amg_hip_status amg_hip_capture_end(void* stream, void** graph_exec) {
+  if (!graph_exec) return fail(AMG_HIP_EINVAL, "bad argument");
+  hipGraph_t g = nullptr;
+  HIP_TRY(hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t ex = nullptr;
+  hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return fail(AMG_HIP_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+  *graph_exec = ex;
+  return AMG_HIP_OK;
+}
+amg_hip_status amg_hip_graph_launch(void* graph_exec, void* stream) {
+  if (!graph_exec) return fail(AMG_HIP_EINVAL, "bad argument");
+  HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return AMG_HIP_OK;
+}
+void amg_hip_graph_destroy(void* graph_exec) {
+  if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+}
+
 // ---- generators -----------------------------------------------------------------
 int64_t amg_hip_laplacian(int32_t dim, int64_t n, int32_t* colptr, int32_t* rowind,
                           double* val) {

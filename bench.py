@@ -168,9 +168,15 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=2048, help="grid of the CPU baseline sample")
     ap.add_argument("--cpu-cycles", type=int, default=5)
     ap.add_argument("--profile-launches", type=int, default=40)
-    ap.add_argument("--comm", choices=["auto", "p2p", "ipc"], default="auto",
-                    help="multi-GPU halo exchange: torch.distributed isend/irecv (RCCL) or direct "
-                         "hipIpc pushes; auto = time both, keep the faster one that matches")
+    ap.add_argument("--comm", choices=["auto", "p2p", "ipc", "graph"], default="auto",
+                    help="multi-GPU halo exchange: p2p = torch.distributed isend/irecv (RCCL); ipc = "
+                         "direct hipIpc pushes with stream memory ops; graph = pushes + flags as "
+                         "kernels, one hipGraph per rank; auto = time all, keep the fastest that "
+                         "reproduces the p2p result bit for bit")
+    ap.add_argument("--dist-min-rows-ipc", type=int, default=2000000)
+    ap.add_argument("--dist-min-rows-graph", type=int, default=250000)
+    ap.add_argument("--comm-timeout", type=float, default=180.0,
+                    help="seconds after which a hung alternative exchange mode is abandoned")
     ap.add_argument("--dist-min-rows", type=int, default=6000000,
                     help="multi-GPU: levels with fewer rows (in total) run redundantly on every rank")
     args = ap.parse_args()

@@ -342,6 +342,51 @@ typedef struct {
 amg_hip_status amg_hip_halo_push_wait(const amg_hip_halo_desc* d, void* stream);
 amg_hip_status amg_hip_halo_ack(const amg_hip_halo_desc* d, void* stream);
 
+/* The same exchange as ONE graph-capturable kernel (no host-side stream memory
+ * operations, which cost ~3 us each and cannot be captured): flags are 0/1 words
+ * in the receiver's arena (DATA: "your halo slots hold my new values", FREE: "I
+ * have consumed them"), accessed with system-scope atomics; spins are bounded
+ * (~2 s) and report through *timeout (a device word the host can check).
+ * FREE words must be initialised to 1 (amg_hip_fill_u32), DATA words to 0.      */
+typedef struct {
+  double* dst_prev; const double* src_prev; int64_t cnt_prev;   /* counts in doubles */
+  double* dst_next; const double* src_next; int64_t cnt_next;
+  uint32_t* my_free_from_prev; uint32_t* my_free_from_next;     /* in MY arena        */
+  uint32_t* data_at_prev; uint32_t* data_at_next;               /* in the neighbours' */
+  uint32_t* my_data_from_prev; uint32_t* my_data_from_next;     /* in MY arena        */
+  int32_t recv_prev, recv_next;
+  uint32_t* timeout;
+} amg_hip_halo_kdesc;
+amg_hip_status amg_hip_halo_exchange_kernel(const amg_hip_halo_kdesc* d, void* stream);
+/* after the kernel that consumed the halos: FREE := 1 at the senders */
+amg_hip_status amg_hip_halo_ack_kernel(uint32_t* free_at_prev, uint32_t* free_at_next,
+                                       void* stream);
+/* All-gather by direct pushes: my `cnt` doubles go to offset `off` of every rank's
+ * full vector dst[g] (dst[rank] is my own); data_at[g] / free_at[g] are word [rank]
+ * of rank g's DATA / FREE block, my_data_from / my_free_from my own blocks
+ * (one word per rank).  world <= 16.                                          */
+typedef struct {
+  int32_t rank, world;
+  const double* src; int64_t cnt, off;
+  double* dst[16];
+  uint32_t* data_at[16];
+  uint32_t* free_at[16];
+  uint32_t* my_data_from;
+  uint32_t* my_free_from;
+  uint32_t* timeout;
+} amg_hip_gather_kdesc;
+amg_hip_status amg_hip_gather_kernel(const amg_hip_gather_kdesc* d, void* stream);
+amg_hip_status amg_hip_gather_ack_kernel(const amg_hip_gather_kdesc* d, void* stream);
+amg_hip_status amg_hip_fill_u32(uint32_t* dev_ptr, int64_t count, uint32_t value, void* stream);
+
+/* Stream capture helpers for hosts that drive the launchers above from another
+ * language: everything enqueued on `stream` between begin and end becomes one
+ * executable graph.                                                            */
+amg_hip_status amg_hip_capture_begin(void* stream);
+amg_hip_status amg_hip_capture_end(void* stream, void** graph_exec);
+amg_hip_status amg_hip_graph_launch(void* graph_exec, void* stream);
+void amg_hip_graph_destroy(void* graph_exec);
+
 #ifdef __cplusplus
 }
 #endif

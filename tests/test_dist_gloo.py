@@ -66,6 +66,8 @@ def _worker(rank, world, port, n, L, cycles, agg, sweeps, omega, out_dir, use_pr
         dv.vcycle()
         rss.append(dv.rss())
     u = dv.gather_solution()
+    if hasattr(dv, "timed_out"):
+        assert not dv.timed_out(), "a bounded spin of the in-kernel halo protocol gave up"
     if rank == 0:
         np.savez(os.path.join(out_dir, "out.npz"), u=u, rss=np.array(rss), n_dist=dv.n_dist)
     if hasattr(dv, "close"):
@@ -143,6 +145,23 @@ def test_sharded_vcycle_hipipc_halo_exchange_on_one_gpu(tmp_path, oracle, world)
     GPU 0; gloo only bootstraps (handles, layout tables) and carries the all-gather."""
     n, L, cycles = 96, 7, 4
     got = _run(tmp_path, world, n, L, cycles, agg=900, gpu=True, comm="ipc")
+    assert int(got["n_dist"]) >= 3
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
+    for c in range(cycles):
+        ref.vcycle()
+        assert abs(got["rss"][c] - ref.rss()) <= 1e-12 * ref.rss()
+    assert np.array_equal(got["u"], ref.get_vec(0, "u"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_vcycle_in_graph_exchange_on_one_gpu(tmp_path, oracle, world):
+    """comm="graph": halo exchange and the agglomeration all-gather are kernels with
+    in-kernel 0/1 flags (bounded spins), and from the second cycle on the whole
+    sharded V-cycle is ONE hipGraph replay per rank."""
+    n, L, cycles = 96, 7, 5
+    got = _run(tmp_path, world, n, L, cycles, agg=900, gpu=True, comm="graph")
     assert int(got["n_dist"]) >= 3
     A, b = oracle.laplacian(n), oracle.rhs(n)
     ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
