@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void sell_kernel(
     int n, const int64_t* __restrict__ soff, const int32_t* __restrict__ scol,
     const double* __restrict__ sval, const double* x, const double* __restrict__ f,
     double* out, double omega, const int32_t* __restrict__ rowid, int row0,
-    const double* __restrict__ uH, int nH) {
+    const double* __restrict__ uH, int nH, int dshift) {
   // CSR_JACOBI_P: x is not the smoother's input yet -- the input is x + P uH
   // (LinearInterpolator prolongation, interpolator.hpp:106-129), formed on the
   // fly per gathered entry in the same order as K-ProlongAdd:
@@ -244,10 +244,13 @@ __global__ __launch_bounds__(256) void sell_kernel(
     row = live ? rowid[p] : -1;
     live = row >= 0;
   }
+  // column of row's diagonal: row itself, or row + dshift when x is a rank's
+  // halo-extended vector and the columns are numbered in it (multi-GPU shards)
+  const int drow = row + dshift;
   double fi = 0.0, xi = 0.0;
   if (live) {
     if (MODE != CSR_SPMV) fi = f[row];
-    if (MODE == CSR_JACOBI || MODE == CSR_GS) xi = x[row];
+    if (MODE == CSR_JACOBI || MODE == CSR_GS) xi = x[drow];
     if (MODE == CSR_JACOBI_P) xi = corrected(row);
   }
   double acc = (MODE == CSR_RESID) ? fi : 0.0;
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void sell_kernel(
         if (MODE == CSR_RESID) {
           acc -= v[u] * xx[u];
         } else if (MODE == CSR_JACOBI || MODE == CSR_GS || MODE == CSR_JACOBI_P) {
-          if (c[u] == row) diag = v[u];
+          if (c[u] == drow) diag = v[u];
           else acc += v[u] * xx[u];
         } else {
           acc += v[u] * xx[u];
@@ -309,22 +312,24 @@ static hipError_t launch_sell_mode(int64_t n, int /*max_width*/, const int64_t* 
                                    const int32_t* scol, const double* sval, const double* x,
                                    const double* f, double* out, double omega,
                                    const int32_t* rowid, int64_t row0, int64_t count,
-                                   const double* uH, int64_t nH, hipStream_t st) {
+                                   const double* uH, int64_t nH, hipStream_t st,
+                                   int64_t diag_shift = 0) {
   const unsigned grid = (unsigned)((count + 255) / 256);
   hipLaunchKernelGGL((sell_kernel<MODE>), dim3(grid), dim3(256), 0, st, (int)n, soff, scol, sval,
-                     x, f, out, omega, rowid, (int)row0, uH, (int)nH);
+                     x, f, out, omega, rowid, (int)row0, uH, (int)nH, (int)diag_shift);
   return hipGetLastError();
 }
 hipError_t launch_sell(int mode, int64_t n, int max_width, const int64_t* soff,
                        const int32_t* scol, const double* sval, const double* x,
-                       const double* f, double* out, double omega, hipStream_t st) {
+                       const double* f, double* out, double omega, int64_t diag_shift,
+                       hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  if (n >= ((int64_t)1 << 31) - 256) return hipErrorInvalidValue;
+  if (n >= ((int64_t)1 << 31) - 256 || diag_shift >= ((int64_t)1 << 30)) return hipErrorInvalidValue;
   switch (mode) {
-    case CSR_RESID: return launch_sell_mode<CSR_RESID>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, nullptr, 0, st);
-    case CSR_JACOBI: return launch_sell_mode<CSR_JACOBI>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, nullptr, 0, st);
-    case CSR_SPMV: return launch_sell_mode<CSR_SPMV>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, nullptr, 0, st);
-    case CSR_RSSQ: return launch_sell_mode<CSR_RSSQ>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, nullptr, 0, st);
+    case CSR_RESID: return launch_sell_mode<CSR_RESID>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, nullptr, 0, st, diag_shift);
+    case CSR_JACOBI: return launch_sell_mode<CSR_JACOBI>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, nullptr, 0, st, diag_shift);
+    case CSR_SPMV: return launch_sell_mode<CSR_SPMV>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, nullptr, 0, st, diag_shift);
+    case CSR_RSSQ: return launch_sell_mode<CSR_RSSQ>(n, max_width, soff, scol, sval, x, f, out, omega, nullptr, 0, n, nullptr, 0, st, diag_shift);
   }
   return hipErrorInvalidValue;
 }

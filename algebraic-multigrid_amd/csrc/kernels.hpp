@@ -23,7 +23,8 @@ hipError_t launch_csr(int mode, int64_t n, int64_t nnz, int max_block_nnz,
 // soff[n/64 + 1] panel offsets, scol/sval padded with col = -1.
 hipError_t launch_sell(int mode, int64_t n, int max_width, const int64_t* soff,
                        const int32_t* scol, const double* sval, const double* x,
-                       const double* f, double* out, double omega, hipStream_t st);
+                       const double* f, double* out, double omega, int64_t diag_shift,
+                       hipStream_t st);
 // out = Jacobi sweep applied to (u + P uH), P = LinearInterpolator prolongation:
 // prolongation + add (multigrid.hpp:294-296) fused into the first post-smoothing
 // sweep; u itself is not modified.

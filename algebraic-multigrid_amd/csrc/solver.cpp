@@ -177,13 +177,13 @@ hipError_t upload_mat(const Sparse& M, int layout, DevMat* D) {
 }
 
 hipError_t launch_mat(int mode, const DevMat& A, const double* x, const double* f, double* out,
-                      double omega, hipStream_t st) {
+                      double omega, hipStream_t st, int64_t diag_shift = 0) {
   if (A.sell)
     return launch_sell(mode, A.n_rows, A.max_width, A.soff.as<int64_t>(), A.scol.as<int32_t>(),
-                       A.sval.as<double>(), x, f, out, omega, st);
+                       A.sval.as<double>(), x, f, out, omega, diag_shift, st);
   const DevCsr& C = A.csr;
   return launch_csr(mode, C.n_rows, C.nnz, C.max_block_nnz, C.max_row_nnz, C.rowptr(), C.col(),
-                    C.v(), x, f, out, omega, 0, st);
+                    C.v(), x, f, out, omega, diag_shift, st);
 }
 
 struct LexOnDev {
@@ -1379,6 +1379,52 @@ amg_hip_status amg_hip_dev_jacobi_from_zero(int64_t nrows, const double* diag, c
   HIP_TRY(launch_jacobi_from_zero(nrows, diag, b, u_out, omega, (hipStream_t)stream));
   return AMG_HIP_OK;
 }
+// ---- device matrix object: a local CSR block uploaded in the solver's own layout ----
+struct amg_hip_devmat_impl {
+  DevMat m;
+  int device = 0;
+};
+amg_hip_status amg_hip_devmat_create(int64_t nrows, int64_t ncols, const int32_t* rowptr,
+                                     const int32_t* col, const double* val, int32_t layout,
+                                     int32_t device, amg_hip_devmat** out) {
+  if (!out || nrows < 0 || ncols < 0 || !rowptr || (rowptr[nrows] > 0 && (!col || !val)))
+    return fail(AMG_HIP_EINVAL, "bad argument");
+  amg_hip_status st0 = need_device();
+  if (st0 != AMG_HIP_OK) return st0;
+  Sparse M = from_raw(nrows, ncols, rowptr, col, val);
+  std::string v = validate(M, "local matrix");
+  if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
+  std::unique_ptr<amg_hip_devmat_impl> d(new amg_hip_devmat_impl);
+  if (device < 0) HIP_TRY(hipGetDevice(&device));
+  HIP_TRY(hipSetDevice(device));
+  d->device = device;
+  HIP_TRY(upload_mat_pruned(M, layout, true, &d->m));
+  *out = reinterpret_cast<amg_hip_devmat*>(d.release());
+  return AMG_HIP_OK;
+}
+void amg_hip_devmat_destroy(amg_hip_devmat* h) {
+  auto* d = reinterpret_cast<amg_hip_devmat_impl*>(h);
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  delete d;
+}
+amg_hip_status amg_hip_devmat_apply(const amg_hip_devmat* h, int32_t op, const double* x,
+                                    const double* f, double* out, double omega,
+                                    int64_t diag_shift, void* stream) {
+  auto* d = reinterpret_cast<const amg_hip_devmat_impl*>(h);
+  if (!d || !x || !out) return fail(AMG_HIP_EINVAL, "bad argument");
+  int mode;
+  switch (op) {
+    case 0: mode = CSR_RESID; break;
+    case 1: mode = CSR_JACOBI; break;
+    case 2: mode = CSR_SPMV; break;
+    default: return fail(AMG_HIP_EINVAL, "unknown operation");
+  }
+  if (mode != CSR_SPMV && !f) return fail(AMG_HIP_EINVAL, "bad argument");
+  HIP_TRY(launch_mat(mode, d->m, x, f, out, omega, (hipStream_t)stream, diag_shift));
+  return AMG_HIP_OK;
+}
+
 amg_hip_status amg_hip_dev_axpy1(int64_t n, const double* x, double* y, void* stream) {
   if (n < 0 || !x || !y) return fail(AMG_HIP_EINVAL, "bad argument");
   HIP_TRY(launch_add_inplace(n, x, y, (hipStream_t)stream));

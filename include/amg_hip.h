@@ -289,6 +289,19 @@ amg_hip_status amg_hip_dev_spmv(int64_t nrows, int64_t nnz, int32_t max_block_nn
                                 int32_t max_row_nnz, const int32_t* rowptr,
                                 const int32_t* col, const double* val,
                                 const double* v, double* out, void* stream);
+/* The same three operations on a matrix the LIBRARY uploads in its own device
+ * layout (SELL-64 panels unless `layout` says otherwise; exact zeros dropped):
+ * rows x cols local CSR block given on the host, columns indexing the vector the
+ * operation is applied to.  op: 0 = residual (out = f - A x), 1 = Jacobi sweep
+ * (diagonal of row i at column i + diag_shift), 2 = SpMV (f unused).           */
+typedef struct amg_hip_devmat amg_hip_devmat;
+amg_hip_status amg_hip_devmat_create(int64_t nrows, int64_t ncols, const int32_t* rowptr,
+                                     const int32_t* col, const double* val, int32_t layout,
+                                     int32_t device, amg_hip_devmat** out);
+void amg_hip_devmat_destroy(amg_hip_devmat* m);
+amg_hip_status amg_hip_devmat_apply(const amg_hip_devmat* m, int32_t op, const double* x,
+                                    const double* f, double* out, double omega,
+                                    int64_t diag_shift, void* stream);
 /* First Jacobi sweep from a zero vector: u_out[i] = 0 + omega*((b[i] - 0)/diag[i] - 0)
  * (diag[i] == 0 leaves 0); bit-identical to amg_hip_dev_jacobi on u_in == 0.   */
 amg_hip_status amg_hip_dev_jacobi_from_zero(int64_t nrows, const double* diag,
