@@ -98,6 +98,7 @@ _SIGS = {
     "amg_hip_zero_vec": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "amg_hip_coarse_halfbw": (C.c_int64, [C.c_void_p]),
     "amg_hip_get_colors": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p]),
+    "amg_hip_level_op": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "amg_hip_cycle_bytes": (C.c_int, [C.c_void_p, _f64p, _f64p]),
     "amg_hip_profile_fine_sweep": (C.c_int, [C.c_void_p, C.c_int32, _f64p, _f64p]),
     "amg_hip_smooth": (C.c_int, [C.c_int32, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p,
@@ -121,7 +122,8 @@ _SIGS = {
     "amg_hip_dev_spmv": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "amg_hip_devmat_create": (C.c_int, [C.c_int64, C.c_int64, _i32p, _i32p, _f64p, C.c_int32,
-                                        C.c_int32, C.POINTER(C.c_void_p)]),
+                                        C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "amg_hip_set_index16": (None, [C.c_int32]),
     "amg_hip_devmat_destroy": (None, [C.c_void_p]),
     "amg_hip_devmat_apply": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_double, C.c_int64, C.c_void_p]),
@@ -194,6 +196,10 @@ def device_count():
 
 def set_default_layout(layout):
     lib().amg_hip_set_default_layout(layout)
+
+
+def set_index16(on):
+    lib().amg_hip_set_index16(int(on))
 
 
 # ---- Grid<double> ------------------------------------------------------------
@@ -366,6 +372,10 @@ class Multigrid:
         a, b = C.c_double(0), C.c_double(0)
         _chk(lib().amg_hip_profile_fine_sweep(self._h, n_launches, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def level_op(self, level, op):
+        """op: 0 smooth (built-in), 1 residual, 2 zero+restrict, 3 prolong+add, 4 coarse solve."""
+        _chk(lib().amg_hip_level_op(self._h, level, op))
 
     def vcycle(self, n=1):
         _chk(lib().amg_hip_vcycles(self._h, n))

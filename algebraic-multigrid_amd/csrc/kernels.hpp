@@ -21,15 +21,16 @@ hipError_t launch_csr(int mode, int64_t n, int64_t nnz, int max_block_nnz,
                       double* out, double omega, int64_t diag_shift, hipStream_t st);
 // Same operations on a SELL-64 matrix (64-row panels, lane-interleaved):
 // soff[n/64 + 1] panel offsets, scol/sval padded with col = -1.
-hipError_t launch_sell(int mode, int64_t n, int max_width, const int64_t* soff,
-                       const int32_t* scol, const double* sval, const double* x,
+// idx16 != 0: scol holds int16 offsets from the diagonal column (pad -32768)
+hipError_t launch_sell(int mode, int64_t n, int idx16, const int64_t* soff,
+                       const void* scol, const double* sval, const double* x,
                        const double* f, double* out, double omega, int64_t diag_shift,
                        hipStream_t st);
 // out = Jacobi sweep applied to (u + P uH), P = LinearInterpolator prolongation:
 // prolongation + add (multigrid.hpp:294-296) fused into the first post-smoothing
 // sweep; u itself is not modified.
-hipError_t launch_sell_jacobi_prolong(int64_t n, int max_width, const int64_t* soff,
-                                      const int32_t* scol, const double* sval, const double* u,
+hipError_t launch_sell_jacobi_prolong(int64_t n, int idx16, const int64_t* soff,
+                                      const void* scol, const double* sval, const double* u,
                                       const double* uH, int64_t nH, const double* f, double* out,
                                       double omega, hipStream_t st);
 // out = Jacobi sweep applied to u == 0: needs only the diagonal and f.

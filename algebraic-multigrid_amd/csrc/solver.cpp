@@ -117,8 +117,11 @@ struct DevMat {
   DevCsr csr;                 // K-CSR (LDS-staged CSR)
   int max_width = 0;          // K-SELL (64-row panels, lane-interleaved)
   int64_t slots = 0;
+  int idx16 = 0;              // scol = int16 offsets from the diagonal column
   DevMem soff, scol, sval;
 };
+
+int g_index16 = 1;  // use 16-bit relative column indices when a matrix allows it
 
 int g_default_layout = AMG_HIP_LAYOUT_AUTO;
 
@@ -143,19 +146,27 @@ Sparse without_exact_zeros(const Sparse& M) {
   return R;
 }
 
-hipError_t upload_mat(const Sparse& M, int layout, DevMat* D);
+hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift, bool allow16);
 
-hipError_t upload_mat_pruned(const Sparse& M, int layout, bool prune, DevMat* D) {
-  if (!prune) return upload_mat(M, layout, D);
+hipError_t upload_mat_pruned(const Sparse& M, int layout, bool prune, DevMat* D,
+                             int64_t diag_shift = 0) {
   bool any = false;
-  for (double v : M.val)
-    if (v == 0.0) { any = true; break; }
-  if (!any) return upload_mat(M, layout, D);
-  return upload_mat(without_exact_zeros(M), layout, D);
+  if (prune)
+    for (double v : M.val)
+      if (v == 0.0) { any = true; break; }
+  if (!any) return upload_mat(M, layout, D, diag_shift, true);
+  return upload_mat(without_exact_zeros(M), layout, D, diag_shift, true);
 }
 
 // layout: AMG_HIP_LAYOUT_*; AUTO takes SELL-64 unless padding exceeds 25 %.
+// diag_shift: column of row i's diagonal is i + diag_shift (0 except for the
+// halo-extended local blocks of the multi-GPU driver); only used to decide
+// whether 16-bit relative column indices fit.
+hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift, bool allow16);
 hipError_t upload_mat(const Sparse& M, int layout, DevMat* D) {
+  return upload_mat(M, layout, D, 0, true);
+}
+hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift, bool allow16) {
   D->n_rows = M.n_outer;
   D->nnz = M.nnz();
   bool sell = layout == AMG_HIP_LAYOUT_SELL;
@@ -172,14 +183,38 @@ hipError_t upload_mat(const Sparse& M, int layout, DevMat* D) {
   D->slots = S.slots();
   hipError_t e;
   if ((e = upload(D->soff, S.soff.data(), S.soff.size())) != hipSuccess) return e;
-  if ((e = upload(D->scol, S.col.data(), S.col.size())) != hipSuccess) return e;
+  // 16-bit relative indices when every entry is within +-32767 of its row's diagonal
+  bool fits = allow16 && g_index16 != 0;
+  std::vector<int16_t> c16;
+  if (fits) {
+    c16.assign(S.col.size(), (int16_t)-32768);
+    const int64_t np = (int64_t)S.soff.size() - 1;
+    for (int64_t p = 0; p < np && fits; ++p) {
+      const int64_t w = (S.soff[p + 1] - S.soff[p]) / 64;
+      for (int64_t j = 0; j < w && fits; ++j)
+        for (int64_t l = 0; l < 64; ++l) {
+          const int64_t at = S.soff[p] + j * 64 + l;
+          const int32_t c = S.col[at];
+          if (c < 0) continue;
+          const int64_t d = (int64_t)c - (p * 64 + l + diag_shift);
+          if (d < -32767 || d > 32767) { fits = false; break; }
+          c16[at] = (int16_t)d;
+        }
+    }
+  }
+  D->idx16 = fits ? 1 : 0;
+  if (fits) {
+    if ((e = upload(D->scol, c16.data(), c16.size())) != hipSuccess) return e;
+  } else {
+    if ((e = upload(D->scol, S.col.data(), S.col.size())) != hipSuccess) return e;
+  }
   return upload(D->sval, S.val.data(), S.val.size());
 }
 
 hipError_t launch_mat(int mode, const DevMat& A, const double* x, const double* f, double* out,
                       double omega, hipStream_t st, int64_t diag_shift = 0) {
   if (A.sell)
-    return launch_sell(mode, A.n_rows, A.max_width, A.soff.as<int64_t>(), A.scol.as<int32_t>(),
+    return launch_sell(mode, A.n_rows, A.idx16, A.soff.as<int64_t>(), A.scol.p,
                        A.sval.as<double>(), x, f, out, omega, diag_shift, st);
   const DevCsr& C = A.csr;
   return launch_csr(mode, C.n_rows, C.nnz, C.max_block_nnz, C.max_row_nnz, C.rowptr(), C.col(),
@@ -312,8 +347,8 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0) {
         it = 1;
       } else if (phase == 2 && jacobi_fuses_prolong(s, l)) {
         Level& C = s->lv[l + 1];
-        HIP_TRY(launch_sell_jacobi_prolong(A.n_rows, A.max_width, A.soff.as<int64_t>(),
-                                           A.scol.as<int32_t>(), A.sval.as<double>(), a,
+        HIP_TRY(launch_sell_jacobi_prolong(A.n_rows, A.idx16, A.soff.as<int64_t>(),
+                                           A.scol.p, A.sval.as<double>(), a,
                                            C.u.as<double>(), C.n, L.f.as<double>(), b,
                                            s->opt.omega, st));
         std::swap(a, b);
@@ -561,7 +596,7 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
       build_color_perm(L.A_csc, L.color, L.n_colors, &CP);  // column-as-row walk, like SpGS
       if (CP.rows.n_outer >= ((int64_t)1 << 31) - 512)
         return fail(AMG_HIP_EUNSUPPORTED, "multicolour smoother: level too large for int32 rows");
-      HIP_TRY(upload_mat(CP.rows, AMG_HIP_LAYOUT_SELL, &L.mc_mat));
+      HIP_TRY(upload_mat(CP.rows, AMG_HIP_LAYOUT_SELL, &L.mc_mat, 0, false));
       HIP_TRY(upload(L.mc_rowid, CP.rowid.data(), CP.rowid.size()));
       L.mc_start = CP.start;
     }
@@ -669,6 +704,8 @@ void amg_hip_default_options(amg_hip_options* o) {
   o->stream = nullptr;
 }
 
+void amg_hip_set_index16(int32_t on) { g_index16 = on ? 1 : 0; }
+
 void amg_hip_set_default_layout(int32_t layout) {
   if (layout >= AMG_HIP_LAYOUT_AUTO && layout <= AMG_HIP_LAYOUT_SELL) g_default_layout = layout;
 }
@@ -755,6 +792,53 @@ amg_hip_status amg_hip_zero_vec(amg_hip_solver* s, int32_t level, int32_t which)
   void* v = which == 0 ? L.u.p : (which == 1 ? L.f.p : L.r.p);
   HIP_TRY(hipMemsetAsync(v, 0, sizeof(double) * L.n, s->stream));
   return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_level_op(amg_hip_solver* s, int32_t level, int32_t op) {
+  if (!s) return fail(AMG_HIP_EINVAL, "null solver");
+  const int nl = (int)s->lv.size();
+  if (level < 0 || level >= nl) return fail(AMG_HIP_EINVAL, "level out of range");
+  amg_hip_status r = set_device(s);
+  if (r != AMG_HIP_OK) return r;
+  hipStream_t st = s->stream;
+  Level& L = s->lv[level];
+  switch (op) {
+    case 0: return enqueue_smooth(s, level, 0);
+    case 1: return enqueue_residual(s, level);
+    case 2: {
+      if (level + 1 >= nl) return fail(AMG_HIP_EINVAL, "no coarser level");
+      Level& C = s->lv[level + 1];
+      if (L.linear && s->opt.stencil_transfers) {
+        HIP_TRY(launch_linear_restrict(L.n, C.n, L.r.as<double>(), C.f.as<double>(), C.u.as<double>(), st));
+      } else {
+        HIP_TRY(hipMemsetAsync(C.u.p, 0, sizeof(double) * C.n, st));
+        const DevCsr& R = L.R_rows;
+        HIP_TRY(launch_csr(CSR_SPMV, R.n_rows, R.nnz, R.max_block_nnz, R.max_row_nnz, R.rowptr(),
+                           R.col(), R.v(), L.r.as<double>(), nullptr, C.f.as<double>(), 1.0, 0, st));
+      }
+      return AMG_HIP_OK;
+    }
+    case 3: {
+      if (level + 1 >= nl) return fail(AMG_HIP_EINVAL, "no coarser level");
+      Level& C = s->lv[level + 1];
+      if (L.linear && s->opt.stencil_transfers) {
+        HIP_TRY(launch_linear_prolong_add(L.n, C.n, C.u.as<double>(), L.u.as<double>(), st));
+      } else {
+        const DevCsr& P = L.P_rows;
+        HIP_TRY(launch_csr(CSR_SPMV, P.n_rows, P.nnz, P.max_block_nnz, P.max_row_nnz, P.rowptr(),
+                           P.col(), P.v(), C.u.as<double>(), nullptr, L.tmp.as<double>(), 1.0, 0, st));
+        HIP_TRY(launch_add_inplace(L.n, L.tmp.as<double>(), L.u.as<double>(), st));
+      }
+      return AMG_HIP_OK;
+    }
+    case 4:
+      if (level != nl - 1) return fail(AMG_HIP_EINVAL, "the direct solve belongs to the coarsest level");
+      HIP_TRY(launch_band_solve(s->band_n, s->band_m, s->band_f.as<double>(), s->band_b.as<double>(),
+                                s->band_d.as<double>(), L.f.as<double>(), L.tmp.as<double>(),
+                                L.u.as<double>(), st));
+      return AMG_HIP_OK;
+  }
+  return fail(AMG_HIP_EINVAL, "unknown level operation");
 }
 
 amg_hip_status amg_hip_rss(amg_hip_solver* s, double* out) {
@@ -1383,10 +1467,11 @@ amg_hip_status amg_hip_dev_jacobi_from_zero(int64_t nrows, const double* diag, c
 struct amg_hip_devmat_impl {
   DevMat m;
   int device = 0;
+  int64_t diag_shift = 0;  // the relative column indices were built against this
 };
 amg_hip_status amg_hip_devmat_create(int64_t nrows, int64_t ncols, const int32_t* rowptr,
                                      const int32_t* col, const double* val, int32_t layout,
-                                     int32_t device, amg_hip_devmat** out) {
+                                     int64_t diag_shift, int32_t device, amg_hip_devmat** out) {
   if (!out || nrows < 0 || ncols < 0 || !rowptr || (rowptr[nrows] > 0 && (!col || !val)))
     return fail(AMG_HIP_EINVAL, "bad argument");
   amg_hip_status st0 = need_device();
@@ -1398,7 +1483,8 @@ amg_hip_status amg_hip_devmat_create(int64_t nrows, int64_t ncols, const int32_t
   if (device < 0) HIP_TRY(hipGetDevice(&device));
   HIP_TRY(hipSetDevice(device));
   d->device = device;
-  HIP_TRY(upload_mat_pruned(M, layout, true, &d->m));
+  d->diag_shift = diag_shift;
+  HIP_TRY(upload_mat_pruned(M, layout, true, &d->m, diag_shift));
   *out = reinterpret_cast<amg_hip_devmat*>(d.release());
   return AMG_HIP_OK;
 }
@@ -1421,6 +1507,11 @@ amg_hip_status amg_hip_devmat_apply(const amg_hip_devmat* h, int32_t op, const d
     default: return fail(AMG_HIP_EINVAL, "unknown operation");
   }
   if (mode != CSR_SPMV && !f) return fail(AMG_HIP_EINVAL, "bad argument");
+  // residual / SpMV do not look at the diagonal: they decode the relative column
+  // indices against the shift the matrix was created with
+  if (mode != CSR_JACOBI) diag_shift = d->diag_shift;
+  if (diag_shift != d->diag_shift)
+    return fail(AMG_HIP_EINVAL, "diag_shift differs from the one the matrix was created with");
   HIP_TRY(launch_mat(mode, d->m, x, f, out, omega, (hipStream_t)stream, diag_shift));
   return AMG_HIP_OK;
 }

@@ -135,7 +135,7 @@ class HipBackend:
     def to_numpy(self, t):
         return t.detach().cpu().numpy()
 
-    def matrix(self, rowptr, col, val, ncols=None):
+    def matrix(self, rowptr, col, val, ncols=None, diag_shift=0):
         """Upload a local CSR block in the library's device layout (SELL-64 panels)."""
         import ctypes as C
         rowptr = np.ascontiguousarray(rowptr, np.int32)
@@ -147,7 +147,8 @@ class HipBackend:
         i32, f64 = C.POINTER(C.c_int32), C.POINTER(C.c_double)
         self._chk(self.lib.amg_hip_devmat_create(
             rowptr.size - 1, ncols, rowptr.ctypes.data_as(i32), col.ctypes.data_as(i32),
-            val.ctypes.data_as(f64), self.amg.LAYOUT_AUTO, self.device.index, C.byref(h)))
+            val.ctypes.data_as(f64), self.amg.LAYOUT_AUTO, diag_shift, self.device.index,
+            C.byref(h)))
         self._mats = getattr(self, "_mats", [])
         self._mats.append(h)
         return h
@@ -292,7 +293,7 @@ class DistributedVcycle:
             D = DistLevel()
             D.n, D.s, D.e = sizes[l], s, e
             D.A = LocalMatrix(cp, ri, v, s, e)     # symmetric: CSC arrays == CSR arrays
-            D.mat = backend.matrix(D.A.rowptr, D.A.col, D.A.val)
+            D.mat = backend.matrix(D.A.rowptr, D.A.col, D.A.val, diag_shift=D.A.diag_shift)
             dg = np.zeros(e - s)                    # a_ii of the owned rows
             rows_l = np.repeat(np.arange(e - s), np.diff(D.A.rowptr))
             on_d = D.A.col == rows_l + D.A.diag_shift

@@ -30,6 +30,15 @@ class Multigrid {
   std::vector<Sparse> level_to_coefficient_matrix;  // host copies for the getters
   mutable std::vector<Vector> level_to_soln, level_to_rhs;
   bool display_error{false};
+  bool custom_smoother{false};
+
+  // host round trip for a user-defined smoother on one level
+  void host_smooth(size_t level) {
+    Vector u = fetch(level_to_soln, level, 0);
+    const Vector& f = fetch(level_to_rhs, level, 1);
+    smoother->smooth(level_to_coefficient_matrix[level], u, f);
+    detail::check(amg_hip_set_vec(handle, (int32_t)level, 0, u.data()));
+  }
 
   size_t n_H_dofs_from_n_h_dofs(size_t h_dofs) { return (h_dofs + 1) / 2 - 1; }  // :127-130
 
@@ -79,9 +88,11 @@ class Multigrid {
       opt.smoother = AMG_HIP_SM_JACOBI;
       opt.omega = tj->get_omega();
     } else {
-      throw std::runtime_error(
-          "AMG::Multigrid (MI355X): user-defined SmootherBase subclasses cannot run inside the "
-          "device V-cycle; use SparseGaussSeidel, Jacobi, SuccessiveOverRelaxation or TrueJacobi");
+      // user-defined SmootherBase: its smooth() runs on the host, everything else of the
+      // V-cycle on the device; the device-side smoother is never used
+      custom_smoother = true;
+      opt.smoother = AMG_HIP_SM_JACOBI;
+      opt.smoother_iters = 0;
     }
 
     // level sizes + transfer operators: make_operators runs on the host and
@@ -127,7 +138,23 @@ class Multigrid {
   }
 
   // reference multigrid.hpp:263-305
-  void vcycle() { detail::check(amg_hip_vcycle(handle)); }
+  void vcycle() {
+    if (!custom_smoother) {
+      detail::check(amg_hip_vcycle(handle));
+      return;
+    }
+    for (size_t level = 0; level < n_levels; ++level) {
+      host_smooth(level);                                                   // :268
+      detail::check(amg_hip_level_op(handle, (int32_t)level, 1));          // :272-274
+      if (level + 1 != n_levels)
+        detail::check(amg_hip_level_op(handle, (int32_t)level, 2));        // :278-282
+    }
+    detail::check(amg_hip_level_op(handle, (int32_t)n_levels - 1, 4));     // :287-288
+    for (int level = (int)n_levels - 2; level >= 0; --level) {
+      detail::check(amg_hip_level_op(handle, level, 3));                   // :294-296
+      host_smooth((size_t)level);                                           // :300
+    }
+  }
 
   // reference multigrid.hpp:311-337
   const Vector& solve() {

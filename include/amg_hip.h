@@ -104,6 +104,11 @@ void amg_hip_default_options(amg_hip_options* o);
  * operations below (process-wide; tests flip it to run both kernels).         */
 void amg_hip_set_default_layout(int32_t layout);
 
+/* SELL-64 column indices as 16-bit offsets from the row's diagonal column when
+ * every entry of a matrix is within +-32767 of it (10 instead of 12 bytes per
+ * entry; bit-identical results).  Process-wide, default on.                    */
+void amg_hip_set_index16(int32_t on);
+
 /* Number of usable HIP devices (0 when none; never fails). */
 int amg_hip_device_count(void);
 
@@ -195,6 +200,17 @@ int64_t amg_hip_coarse_halfbw(const amg_hip_solver* s);
  * colour count, so a CPU twin can replay the same colouring.                   */
 amg_hip_status amg_hip_get_colors(const amg_hip_solver* s, int32_t level,
                                   int32_t* color, int32_t* n_colors);
+
+/* Single steps of the V-cycle on one level, for a host that has to interleave its
+ * own code with them: the C++ layer runs a USER-DEFINED SmootherBase subclass on
+ * the host (vectors go device -> host -> smooth() -> device) and
+ * everything else here.  op:
+ *   0 smooth with the solver's built-in smoother           (multigrid.hpp:268,300)
+ *   1 residual r_l = f_l - A_l u_l                          (:272-274)
+ *   2 u_{l+1} = 0 and f_{l+1} = R_l r_l                     (:278-282)
+ *   3 u_l = u_l + P_l u_{l+1}                               (:294-296)
+ *   4 coarsest solve u_L = A_L^-1 f_L (level must be L-1)   (:287-288)        */
+amg_hip_status amg_hip_level_op(amg_hip_solver* s, int32_t level, int32_t op);
 
 /* Sum over levels of the algorithmic HBM bytes of one V-cycle (SURVEY 8(d)
  * formulae) and the per-sweep bytes of level 0; used by bench.py.             */
@@ -293,11 +309,13 @@ amg_hip_status amg_hip_dev_spmv(int64_t nrows, int64_t nnz, int32_t max_block_nn
  * layout (SELL-64 panels unless `layout` says otherwise; exact zeros dropped):
  * rows x cols local CSR block given on the host, columns indexing the vector the
  * operation is applied to.  op: 0 = residual (out = f - A x), 1 = Jacobi sweep
- * (diagonal of row i at column i + diag_shift), 2 = SpMV (f unused).           */
+ * (diagonal of row i at column i + diag_shift), 2 = SpMV (f unused).  The
+ * diag_shift given at creation (0 for a plain matrix) must be the one passed to
+ * apply (the 16-bit relative column indices are built against it).            */
 typedef struct amg_hip_devmat amg_hip_devmat;
 amg_hip_status amg_hip_devmat_create(int64_t nrows, int64_t ncols, const int32_t* rowptr,
                                      const int32_t* col, const double* val, int32_t layout,
-                                     int32_t device, amg_hip_devmat** out);
+                                     int64_t diag_shift, int32_t device, amg_hip_devmat** out);
 void amg_hip_devmat_destroy(amg_hip_devmat* m);
 amg_hip_status amg_hip_devmat_apply(const amg_hip_devmat* m, int32_t op, const double* x,
                                     const double* f, double* out, double omega,

@@ -134,6 +134,40 @@ int main() {
   for (int i = 0; i < 10; ++i) amg2.vcycle();
   CHECK(AMG::rss(amg_A, amg2.get_soln(0), amg_b) < 0.1 * r1);
 
+  // a user-defined SmootherBase subclass (plug-in API, smoother.hpp:18-66): runs on the
+  // host between device steps.  Damped Richardson-Jacobi written against the public
+  // SparseMatrix interface only; must give the TrueJacobi result (same arithmetic).
+  struct UserJacobi : public AMG::SmootherBase<double> {
+    double omega;
+    explicit UserJacobi(double w) : omega(w) { n_iters = 2; }
+    void smooth(const Eigen::SparseMatrix<double>& A, Eigen::Matrix<double, -1, 1>& u,
+                const Eigen::Matrix<double, -1, 1>& b) override {
+      const int* cp = A.outerIndexPtr(); const int* ri = A.innerIndexPtr(); const double* v = A.valuePtr();
+      const Eigen::Index n = A.cols();
+      for (size_t it = 0; it < n_iters; ++it) {
+        Eigen::Matrix<double, -1, 1> t(n);
+        for (Eigen::Index c = 0; c < n; ++c) {
+          double rsum = 0, diag = 0;
+          for (int p = cp[c]; p < cp[c + 1]; ++p) { if (ri[p] == c) diag = v[p]; else rsum += v[p] * u[ri[p]]; }
+          t[c] = diag == 0 ? u[c] : u[c] + omega * ((b[c] - rsum) / diag - u[c]);
+        }
+        u = t;
+      }
+    }
+  };
+  {
+    UserJacobi uj(0.6);
+    AMG::LinearInterpolator<double> interp3(4), interp4(4);
+    AMG::TrueJacobi<double> tj2(0.6, 2);
+    AMG::Multigrid<double> amg_user(&interp3, &uj, amg_A, amg_b, 4, 1e-9, 5, 50);
+    AMG::Multigrid<double> amg_dev(&interp4, &tj2, amg_A, amg_b, 4, 1e-9, 5, 50);
+    for (int i = 0; i < 3; ++i) { amg_user.vcycle(); amg_dev.vcycle(); }
+    auto ua = amg_user.get_soln(0), ub = amg_dev.get_soln(0);
+    bool same = ua.size() == ub.size();
+    for (Eigen::Index i = 0; same && i < ua.size(); ++i) same = (ua[i] == ub[i]);
+    CHECK(same);
+  }
+
   std::cout << (n_failed ? "SOME TESTS FAILED" : "All tests passed") << " (" << n_checks
             << " assertions)" << std::endl;
   return n_failed ? 1 : 0;

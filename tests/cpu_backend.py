@@ -42,7 +42,7 @@ class CpuBackend:
     def to_numpy(self, t):
         return t.detach().numpy()
 
-    def matrix(self, rowptr, col, val):
+    def matrix(self, rowptr, col, val, ncols=None, diag_shift=0):
         return _Ell(rowptr, col, val)
 
     def residual(self, m, u_ext, f, r):

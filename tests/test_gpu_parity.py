@@ -18,13 +18,16 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.fixture(autouse=True, params=["csr", "sell"])
+@pytest.fixture(autouse=True, params=["csr", "sell", "sell_idx32"])
 def layout(request, amg):
-    """Every test runs twice: level matrices as plain CSR (LDS-staged K-CSR
-    kernel) and as SELL-64 panels (K-SELL).  Results must be bit-identical."""
+    """Every test runs three times: level matrices as plain CSR (LDS-staged K-CSR
+    kernel), as SELL-64 panels with 16-bit relative column indices (the default)
+    and as SELL-64 with plain int32 columns.  Results must be bit-identical."""
     amg.set_default_layout(amg.LAYOUT_CSR if request.param == "csr" else amg.LAYOUT_SELL)
+    amg.set_index16(request.param != "sell_idx32")
     yield request.param
     amg.set_default_layout(amg.LAYOUT_AUTO)
+    amg.set_index16(True)
 
 
 def csc(A):
