@@ -124,6 +124,7 @@ _SIGS = {
     "amg_hip_devmat_create": (C.c_int, [C.c_int64, C.c_int64, _i32p, _i32p, _f64p, C.c_int32,
                                         C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "amg_hip_set_index16": (None, [C.c_int32]),
+    "amg_hip_set_nontemporal": (None, [C.c_int32]),
     "amg_hip_devmat_destroy": (None, [C.c_void_p]),
     "amg_hip_devmat_apply": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_double, C.c_int64, C.c_void_p]),

@@ -21,7 +21,8 @@ hipError_t launch_csr(int mode, int64_t n, int64_t nnz, int max_block_nnz,
                       double* out, double omega, int64_t diag_shift, hipStream_t st);
 // Same operations on a SELL-64 matrix (64-row panels, lane-interleaved):
 // soff[n/64 + 1] panel offsets, scol/sval padded with col = -1.
-// idx16 != 0: scol holds int16 offsets from the diagonal column (pad -32768)
+// idx16 bit 0: scol holds int16 offsets from the diagonal column (pad -32768);
+// bit 1: stream the matrix / f / out with non-temporal accesses
 hipError_t launch_sell(int mode, int64_t n, int idx16, const int64_t* soff,
                        const void* scol, const double* sval, const double* x,
                        const double* f, double* out, double omega, int64_t diag_shift,

@@ -122,6 +122,7 @@ struct DevMat {
 };
 
 int g_index16 = 1;  // use 16-bit relative column indices when a matrix allows it
+int g_nontemporal = 1;  // stream large matrices with non-temporal loads
 
 int g_default_layout = AMG_HIP_LAYOUT_AUTO;
 
@@ -202,7 +203,9 @@ hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift
         }
     }
   }
-  D->idx16 = fits ? 1 : 0;
+  // non-temporal matrix stream for matrices well beyond the 256 MiB Infinity Cache
+  const double stream_bytes = (double)S.slots() * (fits ? 10.0 : 12.0);
+  D->idx16 = (fits ? 1 : 0) | ((g_nontemporal && stream_bytes > 192.0e6) ? 2 : 0);
   if (fits) {
     if ((e = upload(D->scol, c16.data(), c16.size())) != hipSuccess) return e;
   } else {
@@ -705,6 +708,7 @@ void amg_hip_default_options(amg_hip_options* o) {
 }
 
 void amg_hip_set_index16(int32_t on) { g_index16 = on ? 1 : 0; }
+void amg_hip_set_nontemporal(int32_t on) { g_nontemporal = on ? 1 : 0; }
 
 void amg_hip_set_default_layout(int32_t layout) {
   if (layout >= AMG_HIP_LAYOUT_AUTO && layout <= AMG_HIP_LAYOUT_SELL) g_default_layout = layout;

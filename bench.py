@@ -69,6 +69,8 @@ def run_single(args):
     import amg_ctypes as amg
     if amg.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (libamg_hip.so has no CPU fallback)")
+    if args.no_nt:
+        amg.lib().amg_hip_set_nontemporal(0)
     t0 = time.time()
     colptr, rowind, val = amg.laplacian(args.n)
     b = amg.rhs(args.n)
@@ -164,6 +166,7 @@ def main():
     ap.add_argument("--sweeps", type=int, default=2, help="Jacobi sweeps per smooth() call")
     ap.add_argument("--smoother", choices=["jacobi", "multicolor"], default="jacobi")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-nt", action="store_true", help="disable the non-temporal matrix stream")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=2048, help="grid of the CPU baseline sample")
     ap.add_argument("--cpu-cycles", type=int, default=5)

@@ -108,6 +108,9 @@ void amg_hip_set_default_layout(int32_t layout);
  * every entry of a matrix is within +-32767 of it (10 instead of 12 bytes per
  * entry; bit-identical results).  Process-wide, default on.                    */
 void amg_hip_set_index16(int32_t on);
+/* Stream matrices larger than ~192 MB with non-temporal loads (process-wide, default
+ * on): the once-read matrix then does not evict the x lines the gathers re-use.  */
+void amg_hip_set_nontemporal(int32_t on);
 
 /* Number of usable HIP devices (0 when none; never fails). */
 int amg_hip_device_count(void);

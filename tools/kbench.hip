@@ -235,6 +235,47 @@ __global__ __launch_bounds__(256) void jac_v3(int n, const int64_t* __restrict__
   if (live) out[row] = (diag == 0.0) ? xi : xi + omega * ((fi - acc) / diag - xi);
 }
 
+// ----------------------------------- V4: SELL-64 with 16-bit relative columns --
+__global__ void sell16_fill(int n, const int64_t* soff, const int32_t* width, const int32_t* scol, int16_t* s16) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int s = r >> 6; const int w = width[s];
+  for (int j = 0; j < w; ++j) { const int64_t at = soff[s] + (int64_t)j * 64 + (r & 63); const int c = scol[at]; s16[at] = c < 0 ? (int16_t)-32768 : (int16_t)(c - r); }
+}
+template <int U, bool NT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void jac_v4(int n, const int64_t* __restrict__ soff,
+    const int16_t* __restrict__ s16, const double* __restrict__ sval, const double* __restrict__ x,
+    const double* __restrict__ f, double* __restrict__ out, double omega) {
+  const int row = blockIdx.x * BLOCK + threadIdx.x;
+  const int s = row >> 6;
+  if (s * 64 >= n) return;
+  const int64_t o0 = soff[s], o1 = soff[s + 1];
+  const int w = (int)((o1 - o0) >> 6);
+  const int64_t base = o0 + (row & 63);
+  const bool live = row < n;
+  double fi = 0, xi = 0;
+  if (live) { fi = NT ? __builtin_nontemporal_load(f + row) : f[row]; xi = x[row]; }
+  double acc = 0, diag = 0;
+  for (int j0 = 0; j0 < w; j0 += U) {
+    int32_t c[U]; double v[U], xx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u < w ? j0 + u : j0;
+      const int d = NT ? __builtin_nontemporal_load(s16 + base + (int64_t)j * 64) : s16[base + (int64_t)j * 64];
+      c[u] = d == -32768 ? -1 : row + d;
+      v[u] = NT ? __builtin_nontemporal_load(sval + base + (int64_t)j * 64) : sval[base + (int64_t)j * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) xx[u] = x[c[u] >= 0 ? c[u] : 0];
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (j0 + u < w && c[u] >= 0) { if (c[u] == row) diag = v[u]; else acc += v[u] * xx[u]; }
+  }
+  if (live) {
+    const double r = (diag == 0.0) ? xi : xi + omega * ((fi - acc) / diag - xi);
+    if (NT) __builtin_nontemporal_store(r, out + row); else out[row] = r;
+  }
+}
+
 // ------------------------------------------------------------------- driver ----
 struct Timer { hipEvent_t a, b; Timer() { CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b)); } };
 
@@ -273,9 +314,13 @@ int main(int argc, char** argv) {
   const int64_t n4 = (int64_t)64 << 20; float4 *ca, *cb; CHECK(hipMalloc(&ca, n4 * 16)); CHECK(hipMalloc(&cb, n4 * 16));
   CHECK(hipMemset(ca, 1, n4 * 16));
 
-  enum { COPY, READ, READ8, READ4, V0, V0b, V1a, V1b, V1c, V2, V3a, V3b, NV };
+  int16_t* s16; CHECK(hipMalloc(&s16, ho[ns] * 2 + 64));
+  sell16_fill<<<(N + 255) / 256, 256>>>((int)N, soff, width, scol, s16);
+  CHECK(hipDeviceSynchronize());
+  enum { COPY, READ, READ8, READ4, V0, V0b, V1a, V1b, V1c, V2, V3a, V3b, V4a, V4b, V4c, V4d, NV };
   const char* names[NV] = {"copy_f4 (1GiB->1GiB, bytes=2GiB)", "read_f4 (1GiB read)", "read 8B/lane (1GiB read)", "read 4B/lane (1GiB read)", "v0 block-staged K6 U8 (product)", "v0 block-staged K6 U5",
-                           "v1 wave-private K6 U8 W4", "v1 wave-private K6 U5 W4", "v1 wave-private K6 U5 W8", "v2 direct CSR U5", "v3 SELL-64 U5", "v3 SELL-64 U8"};
+                           "v1 wave-private K6 U8 W4", "v1 wave-private K6 U5 W4", "v1 wave-private K6 U5 W8", "v2 direct CSR U5", "v3 SELL-64 U5", "v3 SELL-64 U8",
+                           "v4 SELL-64 idx16 U5 (product)", "v4 idx16 nontemporal", "v4 idx16 block 512", "v4 idx16 nt block 1024"};
   std::vector<std::vector<float>> t(NV);
   Timer tm;
   auto run = [&](int v) {
@@ -292,6 +337,10 @@ int main(int argc, char** argv) {
       case V2: jac_v2<5><<<grid256, 256>>>((int)N, rowptr, col, val, x, f, out, omega); break;
       case V3a: jac_v3<5><<<grid256, 256>>>((int)N, soff, width, scol, sval, x, f, out, omega); break;
       case V3b: jac_v3<8><<<grid256, 256>>>((int)N, soff, width, scol, sval, x, f, out, omega); break;
+      case V4a: jac_v4<5, false, 256><<<grid256, 256>>>((int)N, soff, s16, sval, x, f, out, omega); break;
+      case V4b: jac_v4<5, true, 256><<<grid256, 256>>>((int)N, soff, s16, sval, x, f, out, omega); break;
+      case V4c: jac_v4<5, false, 512><<<(unsigned)((N + 511) / 512), 512>>>((int)N, soff, s16, sval, x, f, out, omega); break;
+      case V4d: jac_v4<5, true, 1024><<<(unsigned)((N + 1023) / 1024), 1024>>>((int)N, soff, s16, sval, x, f, out, omega); break;
     }
   };
   // correctness: every variant == V2 (plain CSR) bit for bit
