@@ -737,8 +737,42 @@ __global__ void halo_ack_kernel(uint32_t* free_at_prev, uint32_t* free_at_next) 
     if (free_at_next) __hip_atomic_store(free_at_next, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+// Large halos (3-D: one x-y plane, MBs): same protocol split over three launches so
+// that the copy can use many workgroups.
+__global__ void halo_wait_free_kernel(HaloArgs a) {
+  if (threadIdx.x == 0) {
+    if (a.cnt_prev > 0) spin_until_one(a.my_free_from_prev, a.timeout);
+    if (a.cnt_next > 0) spin_until_one(a.my_free_from_next, a.timeout);
+  }
+}
+__global__ __launch_bounds__(256) void halo_copy_kernel(HaloArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nt = (int64_t)gridDim.x * 256;
+  for (int64_t i = t; i < a.cnt_prev; i += nt) __builtin_nontemporal_store(a.src_prev[i], a.dst_prev + i);
+  for (int64_t i = t; i < a.cnt_next; i += nt) __builtin_nontemporal_store(a.src_next[i], a.dst_next + i);
+  __threadfence_system();
+}
+__global__ void halo_publish_wait_kernel(HaloArgs a) {
+  if (threadIdx.x == 0) {
+    if (a.cnt_prev > 0)
+      __hip_atomic_store(a.data_at_prev, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.cnt_next > 0)
+      __hip_atomic_store(a.data_at_next, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.recv_prev) spin_until_one(a.my_data_from_prev, a.timeout);
+    if (a.recv_next) spin_until_one(a.my_data_from_next, a.timeout);
+    __threadfence_system();
+  }
+}
 hipError_t launch_halo_exchange(const HaloArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(halo_exchange_kernel, dim3(1), dim3(256), 0, st, a);
+  const int64_t big = a.cnt_prev > a.cnt_next ? a.cnt_prev : a.cnt_next;
+  if (big <= 16384) {
+    hipLaunchKernelGGL(halo_exchange_kernel, dim3(1), dim3(256), 0, st, a);
+  } else {
+    int64_t g = (big + 2047) / 2048;
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL(halo_wait_free_kernel, dim3(1), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(halo_copy_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(halo_publish_wait_kernel, dim3(1), dim3(64), 0, st, a);
+  }
   return hipGetLastError();
 }
 hipError_t launch_halo_ack(uint32_t* free_at_prev, uint32_t* free_at_next, hipStream_t st) {

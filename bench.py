@@ -104,12 +104,12 @@ def run_single(args):
     # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run
     # inside this process); only quoted for the configuration it was measured on.
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
     if os.path.exists(pmc) and args.n == 4096:
         rec = json.load(open(pmc))
-        k = rec["kernels"].get("sell_kernel<1, true>@16777216")
+        k = rec["kernels"].get("sell_kernel<1, true, true>@16777216")
         if k and rec.get("n") == args.n:
-            traffic, traffic_src = k["traffic_bytes"], "profiles/r01b_pmc_traffic.md: " + rec["source"]
+            traffic, traffic_src = k["traffic_bytes"], "profiles/r01c_pmc_traffic.md: " + rec["source"]
     out = {
         "metric": "V-cycles/sec, 2D Poisson N=4096^2 (fine-grid smoother HBM GB/s under roofline)",
         "value": args.steps / dt,
@@ -134,7 +134,7 @@ def run_single(args):
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "sell_kernel<CSR_JACOBI, idx16> (level-0 Jacobi sweep, SELL-64 panels)",
+            "kernel": "sell_kernel<CSR_JACOBI, idx16, nt> (level-0 Jacobi sweep, SELL-64 panels)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -39,7 +39,7 @@ class _OracleHierarchy:
 
 
 def _worker(rank, world, port, n, L, cycles, agg, sweeps, omega, out_dir, use_product_hierarchy,
-            gpu=False, comm="p2p"):
+            gpu=False, comm="p2p", dim=2):
     for p in (ROOT, os.path.join(ROOT, "algebraic-multigrid_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -49,7 +49,7 @@ def _worker(rank, world, port, n, L, cycles, agg, sweeps, omega, out_dir, use_pr
     from oracle import oracle as O
     import dist_vcycle
     from cpu_backend import CpuBackend
-    A, b = O.laplacian(n), O.rhs(n)
+    A, b = O.laplacian(n, dim), O.rhs(n, dim)
     if use_product_hierarchy:   # the product's own host setup through the C ABI (no device)
         import amg_ctypes as amg
         hier = amg.Multigrid(A.colptr, A.rowind, A.val, b, L, smoother=amg.SM_JACOBI, host_only=True)
@@ -77,10 +77,10 @@ def _worker(rank, world, port, n, L, cycles, agg, sweeps, omega, out_dir, use_pr
 
 
 def _run(tmp_path, world, n, L, cycles, agg, sweeps=2, omega=0.6, product_hier=True, gpu=False,
-         comm="p2p"):
+         comm="p2p", dim=2):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n, L, cycles, agg, sweeps, omega, str(tmp_path), product_hier,
-                            gpu, comm), nprocs=world, join=True)
+                            gpu, comm, dim), nprocs=world, join=True)
     return np.load(os.path.join(str(tmp_path), "out.npz"))
 
 
@@ -114,6 +114,18 @@ def test_everything_agglomerated(tmp_path, oracle):
     got = _run(tmp_path, 2, n, L, cycles, agg=10 ** 6)
     assert int(got["n_dist"]) == 0
     A, b = oracle.laplacian(n), oracle.rhs(n)
+    ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
+    for _ in range(cycles):
+        ref.vcycle()
+    assert np.array_equal(got["u"], ref.get_vec(0, "u"))
+
+
+def test_sharded_3d_7point(tmp_path, oracle):
+    # BASELINE config 5 shape (3-D 7-point, row-block shards): halo = one x-y plane + 1
+    n, L, cycles = 14, 5, 2
+    got = _run(tmp_path, 2, n, L, cycles, agg=300, dim=3)
+    assert int(got["n_dist"]) >= 2
+    A, b = oracle.laplacian(n, 3), oracle.rhs(n, 3)
     ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
     for _ in range(cycles):
         ref.vcycle()
@@ -186,4 +198,19 @@ def test_sharded_vcycle_hip_kernels_on_one_gpu(tmp_path, oracle, world):
     for c in range(cycles):
         ref.vcycle()
         assert abs(got["rss"][c] - ref.rss()) <= 1e-12 * ref.rss()
+    assert np.array_equal(got["u"], ref.get_vec(0, "u"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("comm", ["ipc", "graph"])
+def test_sharded_3d_large_halos_on_one_gpu(tmp_path, oracle, comm):
+    """3-D 7-point, 136^3 on 2 ranks: the level-0 halo is one x-y plane (18497 doubles),
+    which takes the multi-workgroup variant of the in-graph exchange."""
+    n, L, cycles = 136, 13, 2      # 13 levels: the coarsest half-bandwidth must be <= 63
+    got = _run(tmp_path, 2, n, L, cycles, agg=500000, gpu=True, comm=comm, dim=3)
+    assert int(got["n_dist"]) >= 2
+    A, b = oracle.laplacian(n, 3), oracle.rhs(n, 3)
+    ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
+    for _ in range(cycles):
+        ref.vcycle()
     assert np.array_equal(got["u"], ref.get_vec(0, "u"))
