@@ -6,7 +6,12 @@
 // arithmetic (separate IEEE multiply/add, true divide) is part of
 // the contract and several kernels are bit-exact against the CPU oracle.
 //
-// K-CSR (csr_stage_kernel)  -- residual / true Jacobi / generic SpMV / rss terms
+// K-SELL (sell_kernel)      -- residual / true Jacobi / SpMV / rss terms / one colour
+//   of the multicolour GS on the solver's own matrices: CSR sliced into 64-row
+//   lane-interleaved panels, 16-bit relative column indices, non-temporal matrix
+//   stream (see the comment at the kernel).  The fastest layout measured.
+// K-CSR (csr_stage_kernel)  -- the same operations on plain CSR arrays (device-pointer
+//   API, custom interpolators, fallback when SELL would pad too much).
 //   One 256-thread workgroup owns 256 consecutive rows.  The workgroup's slice
 //   of the CSR column-index and value arrays is contiguous in HBM, so it is
 //   streamed with 16-byte-per-lane coalesced loads into LDS (the per-row
@@ -21,6 +26,8 @@
 // K-GS-lex (gs_lex_window)  -- exact lexicographic Gauss-Seidel, dependency
 //   scheduled (parity mode, latency bound by construction).
 // K-Band   (band_solve)     -- coarsest-level banded LDL^T solve, one wave.
+// K-Halo / K-Gather         -- multi-GPU neighbour exchange and all-gather as
+//   graph-capturable kernels over hipIpc-mapped peer memory.
 // =============================================================================
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -386,36 +393,6 @@ hipError_t launch_sell_gs_color(int64_t n_storage, int /*idx16: rows are permute
   if (n_storage >= ((int64_t)1 << 31) - 256 || (row0 & 63)) return hipErrorInvalidValue;
   return launch_sell_mode<CSR_GS>(n_storage, 0, soff, scol, sval, u, f, u, 1.0, rowid, row0,
                                   count, nullptr, 0, st);
-}
-
-// Device-side scan of the row pointer for the two launch parameters above
-// (used by the device-pointer entry points, where the host has no copy).
-__global__ __launch_bounds__(256) void csr_shape_kernel(int64_t n,
-                                                        const int32_t* __restrict__ rowptr,
-                                                        int32_t* __restrict__ out2) {
-  int mb = 0, mr = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int r = rowptr[i + 1] - rowptr[i];
-    mr = r > mr ? r : mr;
-    if ((i % CSR_BLOCK) == 0) {
-      const int64_t e = i + CSR_BLOCK < n ? i + CSR_BLOCK : n;
-      const int b = rowptr[e] - rowptr[i];
-      mb = b > mb ? b : mb;
-    }
-  }
-  atomicMax(&out2[0], mb);
-  atomicMax(&out2[1], mr);
-}
-hipError_t launch_csr_shape(int64_t n, const int32_t* rowptr, int32_t* out2,
-                            hipStream_t st) {
-  hipError_t e = hipMemsetAsync(out2, 0, 8, st);
-  if (e != hipSuccess) return e;
-  if (n <= 0) return hipSuccess;
-  int64_t g = (n + 255) / 256;
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(csr_shape_kernel, dim3((unsigned)g), dim3(256), 0, st, n, rowptr, out2);
-  return hipGetLastError();
 }
 
 // ------------------------------------------------- K-Restrict / K-ProlongAdd ---

@@ -44,9 +44,6 @@ hipError_t launch_sell_gs_color(int64_t n_storage, int max_width, const int64_t*
                                 const int32_t* scol, const double* sval, const int32_t* rowid,
                                 int64_t row0, int64_t count, const double* f, double* u,
                                 hipStream_t st);
-// out2[0] = max_block_nnz, out2[1] = max_row_nnz (device int32[2])
-hipError_t launch_csr_shape(int64_t n, const int32_t* rowptr, int32_t* out2,
-                            hipStream_t st);
 
 // uH_zero (may be null): coarse solution vector zero-filled in the same pass
 hipError_t launch_linear_restrict(int64_t n_h, int64_t n_H, const double* r, double* fH,

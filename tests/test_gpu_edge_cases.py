@@ -123,3 +123,59 @@ def test_two_solvers_are_independent(amg, oracle):
     assert np.array_equal(m2.get_soln(0), r2.get_vec(0, "u"))
     m1.close()
     m2.close()
+
+
+def test_device_pointer_csr_api(amg, oracle):
+    """amg_hip_dev_* launchers on caller-owned device memory (torch tensors): plain CSR
+    arrays, halo-style column offset (diag_shift), explicit stream."""
+    import ctypes as C
+    import torch
+    A = oracle.laplacian(40)
+    n = A.rows
+    rng = np.random.default_rng(4)
+    u, f = rng.standard_normal(n), rng.standard_normal(n)
+    lib = amg.lib()
+    dev = torch.device("cuda", 0)
+    mb, mr = amg.csr_shape(A.colptr)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rp, ci, va = t(A.colptr), t(A.rowind), t(A.val)          # symmetric: CSC == CSR
+    # vector extended by a fake halo of 7 entries in front: columns shift by 7
+    shift = 7
+    ci_s = t(A.rowind + shift)
+    u_ext = t(np.concatenate([np.full(shift, 1e300), u]))
+    ft, out = t(f), torch.empty(n, dtype=torch.float64, device=dev)
+    st = torch.cuda.Stream(dev)
+    with torch.cuda.stream(st):
+        assert lib.amg_hip_dev_residual(n, A.nnz, mb, mr, rp.data_ptr(), ci_s.data_ptr(), va.data_ptr(),
+                                        u_ext.data_ptr(), ft.data_ptr(), out.data_ptr(), st.cuda_stream) == 0
+        st.synchronize()
+        assert np.array_equal(out.cpu().numpy(), oracle.residual(A, u, f))
+        assert lib.amg_hip_dev_jacobi(n, A.nnz, mb, mr, rp.data_ptr(), ci_s.data_ptr(), va.data_ptr(),
+                                      u_ext.data_ptr(), ft.data_ptr(), out.data_ptr(), 0.7, shift,
+                                      st.cuda_stream) == 0
+        st.synchronize()
+        want, _, _ = oracle.smooth(oracle.SM_TRUE_JACOBI, A, u, f, n_iters=1, omega=0.7)
+        assert np.array_equal(out.cpu().numpy(), want)
+        assert lib.amg_hip_dev_spmv(n, A.nnz, mb, mr, rp.data_ptr(), ci.data_ptr(), va.data_ptr(),
+                                    t(u).data_ptr(), out.data_ptr(), st.cuda_stream) == 0
+        st.synchronize()
+        assert np.array_equal(out.cpu().numpy(), oracle.spmv(A, u))
+        # from-zero sweep == full sweep on a zero vector
+        diag = t(A.to_scipy().diagonal())
+        assert lib.amg_hip_dev_jacobi_from_zero(n, diag.data_ptr(), ft.data_ptr(), out.data_ptr(), 0.7,
+                                                st.cuda_stream) == 0
+        st.synchronize()
+        want, _, _ = oracle.smooth(oracle.SM_TRUE_JACOBI, A, np.zeros(n), f, n_iters=1, omega=0.7)
+        assert np.array_equal(out.cpu().numpy(), want)
+        # y += x and sum of squares
+        y = t(u.copy())
+        assert lib.amg_hip_dev_axpy1(n, ft.data_ptr(), y.data_ptr(), st.cuda_stream) == 0
+        scratch = torch.zeros(1100, dtype=torch.float64, device=dev)
+        assert lib.amg_hip_dev_sumsq(n, ft.data_ptr(), scratch[1024:].data_ptr(), scratch.data_ptr(),
+                                     st.cuda_stream) == 0
+        st.synchronize()
+        assert np.array_equal(y.cpu().numpy(), u + f)
+        assert abs(float(scratch[1024]) - float(np.dot(f, f))) <= 1e-13 * np.dot(f, f)
+    # misaligned matrix arrays are refused, not mis-read
+    assert lib.amg_hip_dev_spmv(n, A.nnz, mb, mr, rp.data_ptr(), ci.data_ptr() + 4, va.data_ptr(),
+                                t(u).data_ptr(), out.data_ptr(), None) == amg.EINVAL
