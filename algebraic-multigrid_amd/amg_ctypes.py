@@ -36,7 +36,8 @@ class Options(C.Structure):
                 ("stencil_transfers", C.c_int32), ("layout", C.c_int32),
                 ("host_only", C.c_int32), ("keep_structural_zeros", C.c_int32),
                 ("no_fusion", C.c_int32), ("fuse_prolong", C.c_int32),
-                ("reserved", C.c_int32 * 3), ("stream", C.c_void_p)]
+                ("fast_coarse_solve", C.c_int32), ("reserved", C.c_int32 * 2),
+                ("stream", C.c_void_p)]
 
 
 class HaloDesc(C.Structure):
@@ -110,6 +111,8 @@ _SIGS = {
     "amg_hip_linear_prolong_add": (C.c_int, [C.c_int64, C.c_int64, _f64p, _f64p]),
     "amg_hip_rss_host": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, _f64p]),
     "amg_hip_coarse_solve": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, _i64p]),
+    "amg_hip_coarse_solve_fast": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, _i64p,
+                                            _i32p]),
     "amg_hip_laplacian": (C.c_int64, [C.c_int32, C.c_int64, _i32p, _i32p, _f64p]),
     "amg_hip_rhs": (C.c_int, [C.c_int32, C.c_int64, _f64p]),
     "amg_hip_csr_shape": (C.c_int, [C.c_int64, _i32p, _i32p, _i32p]),
@@ -232,7 +235,7 @@ class Multigrid:
                  smoother_iters=1, omega=1.0, tolerance=1e-9, compute_error_every_n_iters=10,
                  n_iters=100, device=-1, use_graph=True, stencil_transfers=True,
                  transfers=None, layout=None, host_only=False, keep_structural_zeros=False,
-                 no_fusion=False, fuse_prolong=False, stream=None):
+                 no_fusion=False, fuse_prolong=False, stream=None, fast_coarse_solve=False):
         # multigrid.hpp:165-178 (same checks, same order)
         if compute_error_every_n_iters > n_iters:
             raise ValueError("`compute_error_every_n_iters` must be leq to `n_iters`, got "
@@ -255,6 +258,7 @@ class Multigrid:
         o.keep_structural_zeros = int(keep_structural_zeros)
         o.no_fusion = int(no_fusion)
         o.fuse_prolong = int(fuse_prolong)
+        o.fast_coarse_solve = int(fast_coarse_solve)
         if stream:
             o.stream = C.c_void_p(stream)
         h = C.c_void_p()
@@ -468,6 +472,15 @@ def coarse_solve(colptr, rowind, val, f):
     _chk(lib().amg_hip_coarse_solve(f.size, _p32(colptr), _p32(rowind), _p64(val), _p64(f),
                                     _p64(x), C.byref(w)))
     return x, w.value
+
+
+def coarse_solve_fast(colptr, rowind, val, f):
+    colptr, rowind, val, f = _a32(colptr), _a32(rowind), _a64(val), _a64(f)
+    x = np.empty(f.size, np.float64)
+    w, c = C.c_int64(0), C.c_int32(0)
+    _chk(lib().amg_hip_coarse_solve_fast(f.size, _p32(colptr), _p32(rowind), _p64(val), _p64(f),
+                                         _p64(x), C.byref(w), C.byref(c)))
+    return x, w.value, c.value
 
 
 def csr_shape(rowptr):

@@ -277,6 +277,86 @@ std::string band_schedule(const BandFactor& F, BandSchedule* S) {
   return "";
 }
 
+std::string spike_factor(const BandFactor& F, SpikeFactor* S) {
+  const int64_t n = F.n;
+  const int w = (int)F.w;
+  if (w > 63) return "coarsest operator has half-bandwidth > 63";
+  const int wq = w > 0 ? w : 1;
+  int32_t m = 4;
+  while (m <= w) m *= 2;
+  // a local step costs ~1/8 of an m = 64 boundary step: balance c against n / c
+  int c = 64 * (int)std::ceil(std::sqrt((double)n * m / 8.0) / 64.0);
+  if (c < 64) c = 64;
+  if (c < w) c = ((w + 63) / 64) * 64;
+  const int64_t P = (n + c - 1) / c;
+  S->n = n; S->w = w; S->c = c; S->P = (int32_t)P;
+  S->d = F.d;
+  auto L = [&](int64_t i, int64_t j) -> double {  // L[i, j], i > j, inside the band
+    const int64_t d = i - j;
+    if (j < 0 || i >= n || d < 1 || d > w) return 0.0;
+    return F.lcol[j * w + (d - 1)];
+  };
+  // local schedules: partition p as a stand-alone banded system
+  S->m = m;
+  const int64_t n_pad = (int64_t)(c + 63) / 64 * 64 + 64;
+  S->sched_stride = n_pad * m;
+  S->sched_f.assign((size_t)(P * S->sched_stride), 0.0);
+  S->sched_b.assign((size_t)(P * S->sched_stride), 0.0);
+  for (int64_t p = 0; p < P; ++p) {
+    const int64_t r0 = p * c, nl = std::min<int64_t>(c, n - r0);
+    BandFactor loc;
+    loc.n = nl;
+    loc.w = w;
+    loc.d.assign(F.d.begin() + r0, F.d.begin() + r0 + nl);
+    loc.lcol.assign((size_t)(nl * wq), 0.0);
+    for (int64_t k = 0; k < nl; ++k)
+      for (int d = 1; d <= w && k + d < nl; ++d) loc.lcol[k * wq + (d - 1)] = L(r0 + k + d, r0 + k);
+    BandSchedule bs;
+    std::string e = band_schedule(loc, &bs);
+    if (!e.empty()) return e;
+    std::copy(bs.sched_f.begin(), bs.sched_f.end(), S->sched_f.begin() + p * S->sched_stride);
+    std::copy(bs.sched_b.begin(), bs.sched_b.end(), S->sched_b.begin() + p * S->sched_stride);
+  }
+  // spikes
+  S->V.assign((size_t)n * wq, 0.0);
+  S->W.assign((size_t)n * wq, 0.0);
+  S->Vt.assign((size_t)P * m * m, 0.0);   // zero-padded M x M blocks
+  S->Wh.assign((size_t)P * m * m, 0.0);
+  std::vector<double> col(c);
+  for (int64_t p = 0; p < P; ++p) {
+    const int64_t r0 = p * c, nl = std::min<int64_t>(c, n - r0);
+    if (p > 0)
+      for (int k = 0; k < w; ++k) {      // V_p[:, k] = L_pp^-1 (B_p e_k), e_k = k-th tail entry of p-1
+        const int64_t gj = r0 - w + k;
+        for (int64_t i = 0; i < nl; ++i) {
+          double s = L(r0 + i, gj);
+          for (int d = 1; d <= w && i - d >= 0; ++d) s -= L(r0 + i, r0 + i - d) * col[i - d];
+          col[i] = s;
+          S->V[(size_t)(r0 + i) * wq + k] = s;
+        }
+      }
+    if (p + 1 < P)
+      for (int k = 0; k < w; ++k) {      // W_p[:, k] = L_pp^-T (B_{p+1}^T e_k), e_k = k-th head entry of p+1
+        const int64_t gr = r0 + c + k;
+        for (int64_t i = nl - 1; i >= 0; --i) {
+          double s = L(gr, r0 + i);
+          for (int d = 1; d <= w && i + d < nl; ++d) s -= L(r0 + i + d, r0 + i) * col[i + d];
+          col[i] = s;
+          S->W[(size_t)(r0 + i) * wq + k] = s;
+        }
+      }
+    // boundary blocks, transposed so that lane k reads contiguously: [p][j][k]
+    for (int k = 0; k < w; ++k)
+      for (int j = 0; j < w; ++j) {
+        const int64_t it = r0 + nl - w + k;   // k-th tail row of partition p
+        if (it >= r0) S->Vt[((size_t)p * m + j) * m + k] = S->V[(size_t)it * wq + j];
+        const int64_t ih = r0 + k;            // k-th head row
+        if (ih < r0 + nl) S->Wh[((size_t)p * m + j) * m + k] = S->W[(size_t)ih * wq + j];
+      }
+  }
+  return "";
+}
+
 // ------------------------------------------------- exact lexicographic order ---
 std::string build_lex_schedule(const Sparse& M, bool backward, int32_t max_width,
                                LexSchedule* S) {

@@ -87,6 +87,26 @@ struct BandSchedule {
 // fails when w > 63
 std::string band_schedule(const BandFactor& F, BandSchedule* out);
 
+// Partitioned ("spike") form of the same factor for the parallel coarse solve:
+// the n rows are cut into P partitions of c rows (c a multiple of 64, c >= w).
+// Every partition solves its own triangular system with the one-wave substitution
+// kernel (one workgroup per partition, all in parallel), a short serial recurrence
+// over the partition boundaries (w unknowns each) couples them, and every row
+// corrects itself with its spike row.  Depth ~ 2c + P steps instead of n.
+struct SpikeFactor {
+  int64_t n = 0;
+  int32_t w = 0, c = 0, P = 0, m = 0;
+  int64_t sched_stride = 0;        // doubles between the schedules of two partitions
+  std::vector<double> sched_f;     // P local forward schedules (BandSchedule layout)
+  std::vector<double> sched_b;     // P local backward schedules
+  std::vector<double> d;           // n
+  std::vector<double> V;           // [n][w]  forward spikes  L_pp^-1 B_p     (rows of partition 0: 0)
+  std::vector<double> W;           // [n][w]  backward spikes L_pp^-T B_{p+1}^T (last partition: 0)
+  std::vector<double> Vt;          // [P][m(j)][m(k)]: tail rows of V, k fastest, zero-padded
+  std::vector<double> Wh;          // [P][m(j)][m(k)]: head rows of W, k fastest, zero-padded
+};
+std::string spike_factor(const BandFactor& F, SpikeFactor* out);
+
 // ---- exact lexicographic Gauss-Seidel schedule ------------------------------
 // Rows are executed in `order`; rows inside one window of `block` consecutive
 // slots that depend on an earlier slot of the same window get `depth` > 0.

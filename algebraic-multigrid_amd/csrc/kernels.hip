@@ -912,6 +912,102 @@ __global__ __launch_bounds__(64) void band_solve_kernel(
   band_pass<M, false>(n, lane, sched_b, y, x);          // L^T x = z
 }
 
+// ---------------------------------------------------------------- K-Spike -----
+// Parallel form of the same LDL^T solve (host_setup.cpp: spike_factor): P partitions
+// of c rows.  (A) every partition runs the one-wave substitution above on its own
+// triangular block, one workgroup per partition; (B) one wave walks the P partition
+// boundaries (w unknowns each: t_p = tail(g_p) - Vt_p t_{p-1}); (C) every row
+// subtracts its spike row times the neighbouring boundary vector and divides by D;
+// (D)-(F) mirror it for L^T.  Depth ~ 2c + P steps instead of n.  Same direct solve,
+// different rounding order, so the V-cycle uses it only on request.
+template <int M, bool FWD>
+__global__ __launch_bounds__(64) void spike_local_kernel(SpikeArgs a, const double* rhs,
+                                                         double* out) {
+  const int lane = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * a.c;
+  const int64_t nl = (a.n - r0 < a.c) ? a.n - r0 : a.c;
+  band_pass<M, FWD>(nl, lane, (FWD ? a.sched_f : a.sched_b) + (int64_t)blockIdx.x * a.sched_stride,
+                    rhs + r0, out + r0);
+}
+// forward: q = 0..P-1, block = last w rows of partition q, couples to q-1
+// backward: q = P-1..0, block = first w rows of partition q, couples to q+1
+// Vt/Wh blocks are zero-padded to M x M ([j][k], k fastest), so the matvec is a
+// fixed-length unrolled loop and the next block is fetched while this one is used.
+template <int M, bool FWD>
+__global__ __launch_bounds__(64) void spike_boundary_kernel(SpikeArgs a, const double* g,
+                                                            double* bnd) {
+  const int k = threadIdx.x;
+  const int w = a.w, wq = a.w > 0 ? a.w : 1;
+  const bool act = k < w;
+  const int kc = k < M ? k : 0;
+  const double* blocks = FWD ? a.Vt : a.Wh;
+  double cur[M], nxt[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) cur[j] = 0.0;
+  double t = 0.0;
+  for (int s = 0; s < a.P; ++s) {
+    const int q = FWD ? s : a.P - 1 - s;
+    const int64_t r0 = (int64_t)q * a.c;
+    const int64_t nl = (a.n - r0 < a.c) ? a.n - r0 : a.c;
+    const int64_t row = FWD ? r0 + nl - w + k : r0 + k;
+    const bool ok = act && row >= r0 && row < r0 + nl;
+    double v = g[ok ? row : 0];
+    v = ok ? v : 0.0;
+    if (s + 1 < a.P) {
+      const double* blk = blocks + (int64_t)(FWD ? q + 1 : q - 1) * M * M + kc;
+#pragma unroll
+      for (int j = 0; j < M; ++j) nxt[j] = blk[j * M];
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) v -= cur[j] * readlane_f64(t, j);
+    v = ok ? v : 0.0;
+    if (act) bnd[(int64_t)q * wq + k] = v;
+    t = v;
+#pragma unroll
+    for (int j = 0; j < M; ++j) cur[j] = nxt[j];
+  }
+}
+// forward: out_i = (g_i - V_i . T[p-1]) / D_i ; backward: out_i = g_i - W_i . H[p+1]
+template <bool FWD>
+__global__ __launch_bounds__(256) void spike_correct_kernel(SpikeArgs a, const double* g,
+                                                            const double* bnd, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const int w = a.w, wq = a.w > 0 ? a.w : 1;
+  const int64_t p = i / a.c;
+  double v = g[i];
+  const int64_t nb = FWD ? p - 1 : p + 1;
+  if (nb >= 0 && nb < a.P) {
+    const double* __restrict__ sp = (FWD ? a.V : a.W) + i * wq;
+    const double* __restrict__ t = bnd + nb * wq;
+#pragma unroll 8
+    for (int j = 0; j < w; ++j) v -= sp[j] * t[j];
+  }
+  out[i] = FWD ? v / a.d[i] : v;
+}
+template <int M>
+static hipError_t launch_spike_m(const SpikeArgs& a, hipStream_t st) {
+  const unsigned P = (unsigned)a.P, g = (unsigned)((a.n + 255) / 256);
+  hipLaunchKernelGGL((spike_local_kernel<M, true>), dim3(P), dim3(64), 0, st, a, a.f, a.G);
+  hipLaunchKernelGGL((spike_boundary_kernel<M, true>), dim3(1), dim3(64), 0, st, a, a.G, a.T);
+  hipLaunchKernelGGL((spike_correct_kernel<true>), dim3(g), dim3(256), 0, st, a, a.G, a.T, a.Z);
+  hipLaunchKernelGGL((spike_local_kernel<M, false>), dim3(P), dim3(64), 0, st, a, a.Z, a.G);
+  hipLaunchKernelGGL((spike_boundary_kernel<M, false>), dim3(1), dim3(64), 0, st, a, a.G, a.H);
+  hipLaunchKernelGGL((spike_correct_kernel<false>), dim3(g), dim3(256), 0, st, a, a.G, a.H, a.x);
+  return hipGetLastError();
+}
+hipError_t launch_spike_solve(const SpikeArgs& a, hipStream_t st) {
+  if (a.n <= 0) return hipSuccess;
+  switch (a.m) {
+    case 4: return launch_spike_m<4>(a, st);
+    case 8: return launch_spike_m<8>(a, st);
+    case 16: return launch_spike_m<16>(a, st);
+    case 32: return launch_spike_m<32>(a, st);
+    case 64: return launch_spike_m<64>(a, st);
+  }
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_band_solve(int64_t n, int m, const double* sched_f, const double* sched_b,
                              const double* dg, const double* f, double* y, double* x,
                              hipStream_t st) {

@@ -102,4 +102,17 @@ hipError_t launch_band_solve(int64_t n, int m, const double* sched_f, const doub
                              const double* dg, const double* f, double* y, double* x,
                              hipStream_t st);
 
+// Partitioned coarse solve (K-Spike); arrays as in host_setup.hpp: SpikeFactor.
+struct SpikeArgs {
+  int64_t n;
+  int32_t w, c, P, m;
+  int64_t sched_stride;
+  const double *sched_f, *sched_b, *d, *V, *W, *Vt, *Wh;
+  const double* f;
+  double* x;
+  double *G, *Z;   // scratch, n doubles each
+  double *T, *H;   // scratch, P * max(w,1)
+};
+hipError_t launch_spike_solve(const SpikeArgs& a, hipStream_t st);
+
 }  // namespace amg_hip

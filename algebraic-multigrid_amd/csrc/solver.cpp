@@ -224,6 +224,33 @@ hipError_t launch_mat(int mode, const DevMat& A, const double* x, const double* 
                     C.v(), x, f, out, omega, diag_shift, st);
 }
 
+struct SpikeOnDev {  // device copy of a SpikeFactor + scratch
+  SpikeArgs a{};
+  DevMem sf, sb, d, V, W, Vt, Wh, G, Z, T, H;
+};
+hipError_t upload_spike(const SpikeFactor& S, SpikeOnDev* D) {
+  hipError_t e;
+  if ((e = upload(D->sf, S.sched_f.data(), S.sched_f.size())) != hipSuccess) return e;
+  if ((e = upload(D->sb, S.sched_b.data(), S.sched_b.size())) != hipSuccess) return e;
+  if ((e = upload(D->d, S.d.data(), S.d.size())) != hipSuccess) return e;
+  if ((e = upload(D->V, S.V.data(), S.V.size())) != hipSuccess) return e;
+  if ((e = upload(D->W, S.W.data(), S.W.size())) != hipSuccess) return e;
+  if ((e = upload(D->Vt, S.Vt.data(), S.Vt.size())) != hipSuccess) return e;
+  if ((e = upload(D->Wh, S.Wh.data(), S.Wh.size())) != hipSuccess) return e;
+  const size_t wq = S.w > 0 ? S.w : 1;
+  if ((e = D->G.alloc(sizeof(double) * (size_t)S.n)) != hipSuccess) return e;
+  if ((e = D->Z.alloc(sizeof(double) * (size_t)S.n)) != hipSuccess) return e;
+  if ((e = D->T.alloc(sizeof(double) * (size_t)(S.P + 1) * wq)) != hipSuccess) return e;
+  if ((e = D->H.alloc(sizeof(double) * (size_t)(S.P + 1) * wq)) != hipSuccess) return e;
+  SpikeArgs& a = D->a;
+  a.n = S.n; a.w = S.w; a.c = S.c; a.P = S.P; a.m = S.m; a.sched_stride = S.sched_stride;
+  a.sched_f = D->sf.as<double>(); a.sched_b = D->sb.as<double>(); a.d = D->d.as<double>();
+  a.V = D->V.as<double>(); a.W = D->W.as<double>(); a.Vt = D->Vt.as<double>();
+  a.Wh = D->Wh.as<double>(); a.G = D->G.as<double>(); a.Z = D->Z.as<double>();
+  a.T = D->T.as<double>(); a.H = D->H.as<double>();
+  return hipSuccess;
+}
+
 struct LexOnDev {
   LexDev d;
   DevMem row, depth, win_depth, col, val, src;
@@ -286,6 +313,8 @@ struct amg_hip_solver {
   int64_t band_n = 0, band_w = 0;
   int band_m = 0;
   DevMem band_f, band_b, band_d;
+  // partitioned (parallel) form of the same factor, opt.fast_coarse_solve
+  std::unique_ptr<SpikeOnDev> spike;
   DevMem scratch;   // 1024 doubles + 1 result
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -425,9 +454,16 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
   }
   {                                                                // :287-288
     Level& C = s->lv[nl - 1];
-    HIP_TRY(launch_band_solve(s->band_n, s->band_m, s->band_f.as<double>(),
-                              s->band_b.as<double>(), s->band_d.as<double>(), C.f.as<double>(),
-                              C.tmp.as<double>(), C.u.as<double>(), st));
+    if (s->spike) {
+      SpikeArgs a = s->spike->a;
+      a.f = C.f.as<double>();
+      a.x = C.u.as<double>();
+      HIP_TRY(launch_spike_solve(a, st));
+    } else {
+      HIP_TRY(launch_band_solve(s->band_n, s->band_m, s->band_f.as<double>(),
+                                s->band_b.as<double>(), s->band_d.as<double>(), C.f.as<double>(),
+                                C.tmp.as<double>(), C.u.as<double>(), st));
+    }
   }
   for (int l = nl - 2; l >= 0; --l) {                              // :291
     Level& L = s->lv[l];
@@ -657,6 +693,14 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     BandSchedule S;
     e = band_schedule(F, &S);
     if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
+    if (s->opt.fast_coarse_solve) {
+      SpikeFactor SF;
+      e = spike_factor(F, &SF);
+      if (e.empty()) {
+        s->spike.reset(new SpikeOnDev);
+        HIP_TRY(upload_spike(SF, s->spike.get()));
+      }
+    }
     s->band_n = F.n;
     s->band_w = F.w;
     s->band_m = S.m;
@@ -704,6 +748,7 @@ void amg_hip_default_options(amg_hip_options* o) {
   o->keep_structural_zeros = 0;
   o->no_fusion = 0;
   o->fuse_prolong = 0;
+  o->fast_coarse_solve = 0;
   o->stream = nullptr;
 }
 
@@ -837,6 +882,13 @@ amg_hip_status amg_hip_level_op(amg_hip_solver* s, int32_t level, int32_t op) {
     }
     case 4:
       if (level != nl - 1) return fail(AMG_HIP_EINVAL, "the direct solve belongs to the coarsest level");
+      if (s->spike) {
+        SpikeArgs a = s->spike->a;
+        a.f = L.f.as<double>();
+        a.x = L.u.as<double>();
+        HIP_TRY(launch_spike_solve(a, st));
+        return AMG_HIP_OK;
+      }
       HIP_TRY(launch_band_solve(s->band_n, s->band_m, s->band_f.as<double>(), s->band_b.as<double>(),
                                 s->band_d.as<double>(), L.f.as<double>(), L.tmp.as<double>(),
                                 L.u.as<double>(), st));
@@ -1117,6 +1169,37 @@ amg_hip_status amg_hip_coarse_solve(int64_t n, const int32_t* colptr, const int3
   HIP_TRY(dx.alloc(sizeof(double) * n));
   HIP_TRY(launch_band_solve(n, S.m, dsf.as<double>(), dsb.as<double>(), dd.as<double>(),
                             df.as<double>(), dy.as<double>(), dx.as<double>(), nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(x, dx.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_coarse_solve_fast(int64_t n, const int32_t* colptr, const int32_t* rowind,
+                                         const double* val, const double* f, double* x,
+                                         int64_t* halfbw, int32_t* partition_rows) {
+  amg_hip_status st = need_device();
+  if (st != AMG_HIP_OK) return st;
+  if (n <= 0 || !colptr || !rowind || !val || !f || !x) return fail(AMG_HIP_EINVAL, "bad argument");
+  Sparse A = from_raw(n, n, colptr, rowind, val);
+  std::string v = validate(A, "A");
+  if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
+  BandFactor F;
+  std::string e = band_factor(A, (size_t)8 << 30, &F);
+  if (!e.empty()) return fail(AMG_HIP_EINVAL, e);
+  if (halfbw) *halfbw = F.w;
+  SpikeFactor SF;
+  e = spike_factor(F, &SF);
+  if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
+  if (partition_rows) *partition_rows = SF.c;
+  SpikeOnDev D;
+  DevMem df, dx;
+  HIP_TRY(upload_spike(SF, &D));
+  HIP_TRY(upload(df, f, (size_t)n));
+  HIP_TRY(dx.alloc(sizeof(double) * n));
+  SpikeArgs a = D.a;
+  a.f = df.as<double>();
+  a.x = dx.as<double>();
+  HIP_TRY(launch_spike_solve(a, nullptr));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(x, dx.p, sizeof(double) * n, hipMemcpyDeviceToHost));
   return AMG_HIP_OK;

@@ -80,7 +80,8 @@ def run_single(args):
                            smoother_iters=1, use_graph=not args.no_graph)
     else:
         mg = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_JACOBI,
-                           smoother_iters=args.sweeps, omega=args.omega, use_graph=not args.no_graph)
+                           smoother_iters=args.sweeps, omega=args.omega, use_graph=not args.no_graph,
+                           fast_coarse_solve=args.fast_coarse)
     setup_s = time.time() - t0
     del colptr, rowind, val
     mg.vcycle(args.warmup)
@@ -128,7 +129,7 @@ def run_single(args):
                          f"smoother omega={args.omega} {args.sweeps}+{args.sweeps} sweeps, "
                          f"{L}-level V-cycle, coarsest {sizes[-1]} dofs, fp64, 1xMI355X"),
             "n": args.n, "levels": L, "smoother": args.smoother, "omega": args.omega,
-            "sweeps": args.sweeps, "graph": not args.no_graph,
+            "sweeps": args.sweeps, "graph": not args.no_graph, "fast_coarse_solve": args.fast_coarse,
             "cycle_algorithmic_bytes": cyc_bytes, "cycle_GBps": cyc_bytes / (dt / args.steps) / 1e9,
             "setup_seconds": setup_s, "rss_after_warmup": rss0, "rss_after_steps": rss,
         },
@@ -167,6 +168,8 @@ def main():
     ap.add_argument("--smoother", choices=["jacobi", "multicolor"], default="jacobi")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-nt", action="store_true", help="disable the non-temporal matrix stream")
+    ap.add_argument("--fast-coarse", action="store_true",
+                    help="partitioned (parallel) coarse solve; then fewer levels pay off (--levels 13)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=2048, help="grid of the CPU baseline sample")
     ap.add_argument("--cpu-cycles", type=int, default=5)

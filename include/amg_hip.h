@@ -87,7 +87,12 @@ typedef struct {
                               operations on the same values: bit-identical.       */
   int32_t fuse_prolong;    /* 1: apply the prolongation inside the first post-smoothing
                               Jacobi sweep (bit-identical; measured slower, off)  */
-  int32_t reserved[3];
+  int32_t fast_coarse_solve; /* 1: solve the coarsest system with the partitioned
+                              (parallel) form of the banded LDL^T: depth ~2c+P steps
+                              instead of n.  Same direct solve, different rounding
+                              order: agrees with the sequential substitution to
+                              ~1e-14 relative, not bit for bit.  Default 0.          */
+  int32_t reserved[2];
   void* stream;            /* hipStream_t to run on; NULL (default) = the solver creates
                               and owns a non-blocking stream.  A caller that already
                               orders its device work on a stream (torch's current
@@ -270,6 +275,12 @@ amg_hip_status amg_hip_rss_host(int64_t n, const int32_t* colptr,
 amg_hip_status amg_hip_coarse_solve(int64_t n, const int32_t* colptr,
                                     const int32_t* rowind, const double* val,
                                     const double* f, double* x, int64_t* halfbw);
+
+/* The same solve by the partitioned (parallel) algorithm of opt.fast_coarse_solve. */
+amg_hip_status amg_hip_coarse_solve_fast(int64_t n, const int32_t* colptr,
+                                         const int32_t* rowind, const double* val,
+                                         const double* f, double* x, int64_t* halfbw,
+                                         int32_t* partition_rows);
 
 /* ---- Grid<double> problem generators (grid.hpp), host side -----------------
  * laplacian: grid.hpp:88-98 (dim 2) / 7-point analogue (dim 3).  Call with NULL

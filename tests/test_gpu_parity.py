@@ -471,3 +471,39 @@ def test_jacobi_fusions_and_zero_pruning_are_bit_neutral(amg, oracle):
         mg.vcycle()
     assert np.array_equal(mg.get_soln(0), ref.get_vec(0, "u"))
     mg.close()
+
+
+def test_partitioned_coarse_solve(amg, oracle, mats):
+    """opt.fast_coarse_solve: the banded LDL^T solve cut into partitions that are solved
+    in parallel and coupled by a short boundary recurrence.  Same direct solve as the
+    sequential substitution (and the oracle's), different rounding order: 1e-11 bar."""
+    rng = np.random.default_rng(12)
+    cases = [mats["p2"], mats["p35"], mats["p67_l3"], mats["p67_l4"]]
+    big = oracle.Multigrid(oracle.laplacian(256), oracle.rhs(256), 5)
+    cases += [big.level_matrix(3), big.level_matrix(4)]         # 8191 (w 33) and 4095 (w 17) dofs
+    deep = oracle.Multigrid(oracle.laplacian(128), oracle.rhs(128), 11)
+    cases.append(deep.level_matrix(10))                           # half-bandwidth 2, a few rows
+    for A in cases:
+        f = rng.standard_normal(A.rows)
+        x, w, c = amg.coarse_solve_fast(*csc(A), f)
+        want, w_ref = oracle.band_solve(A, f)
+        assert w == w_ref and c >= max(w, 1)
+        assert rel(x, want) < 1e-11, (A.rows, w, c, rel(x, want))
+        S = A.to_scipy()
+        assert np.linalg.norm(S @ x - f) <= 1e-10 * np.linalg.norm(f) * (1 + abs(S).max() * np.abs(x).max() / np.abs(f).max())
+
+
+def test_vcycle_with_partitioned_coarse_solve_within_1e10(amg, oracle):
+    # north-star tolerance (1e-10 relative) for solution and rss when the coarse solve is
+    # the parallel one; everything else of the cycle stays bit-identical
+    for n, L in ((128, 3), (200, 6)):
+        A, b = oracle.laplacian(n), oracle.rhs(n)
+        ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
+        mg = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6,
+                           fast_coarse_solve=True)
+        for c in range(6):
+            ref.vcycle()
+            mg.vcycle()
+            assert rel(mg.get_soln(0), ref.get_vec(0, "u")) <= 1e-10, (n, c)
+            assert abs(mg.rss() - ref.rss()) <= 1e-10 * ref.rss(), (n, c)
+        mg.close()
