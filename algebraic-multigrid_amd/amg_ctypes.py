@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libamg_hip.so")
 
 OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED = 0, 1, 2, 3, 4
 SM_SPGS, SM_REF_JACOBI, SM_SOR, SM_JACOBI, SM_MULTICOLOR_GS = 0, 1, 2, 3, 4
-LAYOUT_AUTO, LAYOUT_CSR, LAYOUT_SELL = 0, 1, 2
+LAYOUT_AUTO, LAYOUT_CSR, LAYOUT_SELL, LAYOUT_DICT = 0, 1, 2, 3
 
 _i32p = C.POINTER(C.c_int32)
 _f64p = C.POINTER(C.c_double)
@@ -98,6 +98,7 @@ _SIGS = {
     "amg_hip_copy_vec_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "amg_hip_zero_vec": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "amg_hip_coarse_halfbw": (C.c_int64, [C.c_void_p]),
+    "amg_hip_level_layout": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "amg_hip_get_colors": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p]),
     "amg_hip_level_op": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "amg_hip_cycle_bytes": (C.c_int, [C.c_void_p, _f64p, _f64p]),
@@ -128,6 +129,9 @@ _SIGS = {
                                         C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "amg_hip_set_index16": (None, [C.c_int32]),
     "amg_hip_set_nontemporal": (None, [C.c_int32]),
+    "amg_hip_set_dict_rows": (None, [C.c_int32]),
+    "amg_hip_set_xcd_mapping": (None, [C.c_int32]),
+    "amg_hip_set_dict_persistent": (None, [C.c_int32]),
     "amg_hip_devmat_destroy": (None, [C.c_void_p]),
     "amg_hip_devmat_apply": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_double, C.c_int64, C.c_void_p]),
@@ -204,6 +208,18 @@ def set_default_layout(layout):
 
 def set_index16(on):
     lib().amg_hip_set_index16(int(on))
+
+
+def set_dict_rows(rows_per_lane):
+    lib().amg_hip_set_dict_rows(int(rows_per_lane))
+
+
+def set_xcd_mapping(on):
+    lib().amg_hip_set_xcd_mapping(int(on))
+
+
+def set_dict_persistent(blocks_per_cu):
+    lib().amg_hip_set_dict_persistent(int(blocks_per_cu))
 
 
 # ---- Grid<double> ------------------------------------------------------------
@@ -356,6 +372,12 @@ class Multigrid:
 
     def get_tolerance(self):
         return self.tolerance
+
+    def level_layout(self, level):
+        """(layout, matrix stream bytes per sweep) of the level's device operator."""
+        lay, nb = C.c_int32(0), C.c_int64(0)
+        _chk(lib().amg_hip_level_layout(self._h, level, C.byref(lay), C.byref(nb)))
+        return int(lay.value), int(nb.value)
 
     def coarse_halfbw(self):
         return int(lib().amg_hip_coarse_halfbw(self._h))

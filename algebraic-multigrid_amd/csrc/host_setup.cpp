@@ -2,6 +2,8 @@
 #include "host_setup.hpp"
 
 #include <algorithm>
+#include <climits>
+#include <map>
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -203,6 +205,57 @@ void to_sell64(const Sparse& M, Sell64* S) {
       S->val[base + j * 64] = M.val[q];
     }
   }
+}
+
+bool to_dict(const Sparse& M, int64_t diag_shift, DictMat* D) {
+  const int64_t n = M.n_outer;
+  int32_t mw = 0;
+  for (int64_t r = 0; r < n; ++r) mw = std::max(mw, M.ptr[r + 1] - M.ptr[r]);
+  if (mw > 16) return false;
+  D->n = n;
+  D->max_width = mw;
+  D->words = mw > 8 ? 2 : 1;
+  D->doff.clear();
+  D->dval.clear();
+  D->codes.assign((size_t)n * D->words, ~(uint64_t)0);
+  std::map<std::pair<int64_t, uint64_t>, int> table;
+  int prev[16];  // codes of the previous row, tried first (interior rows repeat)
+  for (int j = 0; j < 16; ++j) prev[j] = -1;
+  for (int64_t r = 0; r < n; ++r) {
+    uint64_t w[2] = {~(uint64_t)0, ~(uint64_t)0};
+    int j = 0;
+    for (int32_t q = M.ptr[r]; q < M.ptr[r + 1]; ++q, ++j) {
+      const int64_t d = (int64_t)M.idx[q] - (r + diag_shift);
+      if (d < INT32_MIN / 2 || d > INT32_MAX / 2) return false;
+      uint64_t bits;
+      std::memcpy(&bits, &M.val[q], 8);
+      int code = prev[j];
+      bool hit = false;
+      if (code >= 0 && D->doff[code] == (int32_t)d) {
+        uint64_t tb;
+        std::memcpy(&tb, &D->dval[code], 8);
+        hit = tb == bits;
+      }
+      if (!hit) {
+        auto key = std::make_pair(d, bits);
+        auto it = table.find(key);
+        if (it == table.end()) {
+          if (D->doff.size() >= 255) return false;
+          code = (int)D->doff.size();
+          table.emplace(key, code);
+          D->doff.push_back((int32_t)d);
+          D->dval.push_back(M.val[q]);
+        } else {
+          code = it->second;
+        }
+        prev[j] = code;
+      }
+      w[j >> 3] = (w[j >> 3] & ~((uint64_t)0xFF << (8 * (j & 7)))) | ((uint64_t)code << (8 * (j & 7)));
+    }
+    D->codes[(size_t)r * D->words] = w[0];
+    if (D->words == 2) D->codes[(size_t)r * 2 + 1] = w[1];
+  }
+  return true;
 }
 
 // ------------------------------------------------------------- banded LDL^T ---

@@ -61,6 +61,24 @@ struct Sell64 {
 // rows_as: matrix whose outer index is the row.  Entry order inside a row kept.
 void to_sell64(const Sparse& rows_as, Sell64* out);
 
+// ---- dictionary-coded rows (K-Dict) -------------------------------------------
+// The Galerkin hierarchies of constant-coefficient stencils hold a handful of
+// distinct (column - diagonal column, value) pairs (2-D Poisson: 5 on level 0, <= 60
+// below).  Row r is stored as `words` 64-bit words of byte codes, code k of entry j
+// in byte j (ascending column order kept), 0xFF = no entry; the pairs themselves sit
+// in a table of <= 255 entries.  8 or 16 bytes per row instead of 10-12 per entry,
+// and the decoded values are the original doubles, so results are bit-identical.
+struct DictMat {
+  int64_t n = 0;
+  int32_t words = 1;            // 64-bit code words per row (1: <= 8 entries, 2: <= 16)
+  int32_t max_width = 0;
+  std::vector<uint64_t> codes;  // n * words
+  std::vector<int32_t> doff;    // table: column offset from the row's diagonal column
+  std::vector<double> dval;     // table: value
+};
+// false when the matrix does not qualify (more than 255 pairs or a row > 16 entries)
+bool to_dict(const Sparse& rows_as, int64_t diag_shift, DictMat* out);
+
 // ---- coarsest level: banded LDL^T (replaces Eigen::SimplicialLDLT) ---------
 struct BandFactor {
   int64_t n = 0, w = 0;

@@ -395,6 +395,302 @@ hipError_t launch_sell_gs_color(int64_t n_storage, int /*idx16: rows are permute
                                   count, nullptr, 0, st);
 }
 
+static int g_dict_rows_per_lane = 2;
+static int g_xcd_map = 1;
+static int g_dict_persistent = 0;  // measured no faster than one tile per workgroup
+static int g_dict_blocks_per_cu = 8;
+static int g_dict_force_grid = 0;  // test hook: > 0 = always persistent with this many workgroups
+// ---------------------------------------------------------------- K-Dict -----
+// The same four operations on a dictionary-coded matrix (host_setup.hpp: DictMat).
+// Lane per row; the row's structure is ONE 8- or 16-byte load (byte j = code of
+// entry j, 0xFF = none), the <= 255 (column offset, value) pairs live in LDS.  The
+// matrix stream shrinks from 10-12 bytes per entry to 8/16 bytes per row, which on
+// the 4096^2 fine level leaves f, x and the output as the bulk of the HBM traffic.
+// Entry order (ascending column) and the decoded doubles are the stored ones, so
+// results are bit-identical to K-SELL / K-CSR.
+// R = rows per lane (1 or 2).  R = 2: a lane owns rows 2t and 2t+1, so codes, f and
+// the output move as 16-byte (32-byte for two-word codes) lane accesses and twice as
+// many bytes are in flight per wave (the launcher checks the 16-byte alignment).
+// A row's work is two dependent memory round trips (codes -> table -> x gathers), so
+// large levels run PERSISTENT workgroups that fetch the streamed operands of their
+// next tile before they wait for the gathers of the current one; the table is staged
+// once per workgroup.
+template <int WORDS, int R>
+struct DictStream {  // streamed operands of R rows of one lane
+  uint64_t cw[R][2];
+  double fi[R], xi[R];
+  bool live[R];
+};
+template <int MODE, int WORDS, bool NT, int R>
+__device__ __forceinline__ void dict_fetch(DictStream<WORDS, R>& s, int row0, int n,
+                                           const uint64_t* __restrict__ codes,
+                                           const double* __restrict__ f, const double* x,
+                                           int dshift) {
+  typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    s.live[r] = row0 + r < n;
+    s.cw[r][0] = s.cw[r][1] = ~(uint64_t)0;
+    s.fi[r] = s.xi[r] = 0.0;
+  }
+  if (R == 2 && s.live[R - 1]) {
+    const u64x2* vp = reinterpret_cast<const u64x2*>(codes + (int64_t)row0 * WORDS);
+    const u64x2 a = NT ? __builtin_nontemporal_load(vp) : *vp;
+    if (WORDS == 2) {
+      const u64x2 b2 = NT ? __builtin_nontemporal_load(vp + 1) : vp[1];
+      s.cw[0][0] = a.x; s.cw[0][1] = a.y; s.cw[R - 1][0] = b2.x; s.cw[R - 1][1] = b2.y;
+    } else {
+      s.cw[0][0] = a.x; s.cw[R - 1][0] = a.y;
+    }
+    if (MODE != CSR_SPMV) {
+      const f64x2* fp = reinterpret_cast<const f64x2*>(f + row0);
+      const f64x2 t = NT ? __builtin_nontemporal_load(fp) : *fp;
+      s.fi[0] = t.x; s.fi[R - 1] = t.y;
+    }
+    if (MODE == CSR_JACOBI) { s.xi[0] = x[row0 + dshift]; s.xi[R - 1] = x[row0 + 1 + dshift]; }
+  } else if (s.live[0]) {
+    const uint64_t* cp = codes + (int64_t)row0 * WORDS;
+    if (WORDS == 2) {
+      const u64x2* vp = reinterpret_cast<const u64x2*>(cp);
+      const u64x2 t = NT ? __builtin_nontemporal_load(vp) : *vp;
+      s.cw[0][0] = t.x; s.cw[0][1] = t.y;
+    } else {
+      s.cw[0][0] = NT ? __builtin_nontemporal_load(cp) : cp[0];
+    }
+    if (MODE != CSR_SPMV) s.fi[0] = NT ? __builtin_nontemporal_load(f + row0) : f[row0];
+    if (MODE == CSR_JACOBI) s.xi[0] = x[row0 + dshift];
+  }
+}
+// decode + gather + row arithmetic + store of one tile; `between` runs after the
+// gathers are issued and before their results are used (the next tile's fetch)
+template <int MODE, int WORDS, int UN, bool NT, int R, class Between>
+__device__ __forceinline__ void dict_rows(const DictStream<WORDS, R>& s, int row0,
+                                          const double* s_val, const int32_t* s_off,
+                                          const double* x, double* out, double omega, int dshift,
+                                          Between between) {
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  int c[R][UN];
+  double v[R][UN], xx[R][UN];
+  bool ok[R][UN];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int drow = s.live[r] ? row0 + r + dshift : 0;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int code = (int)((s.cw[r][u >> 3] >> (8 * (u & 7))) & 0xFF);
+      ok[r][u] = code != 0xFF;
+      const int cc = ok[r][u] ? code : 0;
+      c[r][u] = ok[r][u] ? drow + s_off[cc] : 0;  // x[0] is always valid
+      v[r][u] = s_val[cc];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int u = 0; u < UN; ++u) xx[r][u] = x[c[r][u]];
+  between();
+  double res[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int drow = s.live[r] ? row0 + r + dshift : 0;
+    double acc = (MODE == CSR_RESID) ? s.fi[r] : 0.0;
+    double diag = 0.0;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (ok[r][u]) {
+        if (MODE == CSR_RESID) {
+          acc -= v[r][u] * xx[r][u];
+        } else if (MODE == CSR_JACOBI) {
+          if (c[r][u] == drow) diag = v[r][u];
+          else acc += v[r][u] * xx[r][u];
+        } else {
+          acc += v[r][u] * xx[r][u];
+        }
+      }
+    }
+    if (MODE == CSR_RESID || MODE == CSR_SPMV) {
+      res[r] = acc;
+    } else if (MODE == CSR_JACOBI) {
+      res[r] = (diag == 0.0) ? s.xi[r] : s.xi[r] + omega * ((s.fi[r] - acc) / diag - s.xi[r]);
+    } else {
+      const double d = s.fi[r] - acc;
+      res[r] = d * d;
+    }
+  }
+  if (R == 2 && s.live[R - 1]) {
+    f64x2 t;
+    t.x = res[0]; t.y = res[R - 1];
+    f64x2* op = reinterpret_cast<f64x2*>(out + row0);
+    if (NT) __builtin_nontemporal_store(t, op);
+    else *op = t;
+  } else if (s.live[0]) {
+    if (NT) __builtin_nontemporal_store(res[0], out + row0);
+    else out[row0] = res[0];
+  }
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2).  A banded
+// operator re-reads x at +-(half-bandwidth) rows, i.e. a few tiles away, so every XCD
+// gets ONE contiguous run of tiles: the re-reads then hit the L2 that fetched the line
+// (measured on level 1 of the 4096^2 hierarchy: x fetched 2.1x -> see DESIGN.md).
+__device__ __forceinline__ int xcd_tile(unsigned b, unsigned nb, int on) {
+  if (!on) return (int)b;
+  const unsigned k = b & 7u, i = b >> 3, q = nb >> 3, r = nb & 7u;
+  return (int)(k * q + (k < r ? k : r) + i);
+}
+template <int MODE, int WORDS, int UN, bool NT, int R>
+__global__ __launch_bounds__(256) void dict_kernel(
+    int n, const uint64_t* __restrict__ codes, const int32_t* __restrict__ doff,
+    const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
+    double* out, double omega, int dshift, int xcd_map) {
+  __shared__ double s_val[256];
+  __shared__ int32_t s_off[256];
+  const int row0 = (xcd_tile(blockIdx.x, gridDim.x, xcd_map) * 256 + (int)threadIdx.x) * R;
+  DictStream<WORDS, R> s;
+  dict_fetch<MODE, WORDS, NT, R>(s, row0, n, codes, f, x, dshift);  // in flight while the table is staged
+  if ((int)threadIdx.x < ntab) {
+    s_val[threadIdx.x] = dval[threadIdx.x];
+    s_off[threadIdx.x] = doff[threadIdx.x];
+  }
+  __syncthreads();
+  dict_rows<MODE, WORDS, UN, NT, R>(s, row0, s_val, s_off, x, out, omega, dshift, [] {});
+}
+
+// persistent form: workgroup b walks tiles b, b + gridDim.x, ...
+template <int MODE, int WORDS, int UN, bool NT, int R>
+__global__ __launch_bounds__(256) void dict_stream_kernel(
+    int n, int n_tiles, const uint64_t* __restrict__ codes, const int32_t* __restrict__ doff,
+    const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
+    double* out, double omega, int dshift) {
+  __shared__ double s_val[256];
+  __shared__ int32_t s_off[256];
+  int tile = blockIdx.x;
+  DictStream<WORDS, R> cur, nxt;
+  dict_fetch<MODE, WORDS, NT, R>(cur, (tile * 256 + (int)threadIdx.x) * R, n, codes, f, x, dshift);
+  if ((int)threadIdx.x < ntab) {
+    s_val[threadIdx.x] = dval[threadIdx.x];
+    s_off[threadIdx.x] = doff[threadIdx.x];
+  }
+  __syncthreads();
+  while (tile < n_tiles) {  // uniform per workgroup, bounded
+    const int next = tile + (int)gridDim.x;
+    const int row0 = (tile * 256 + (int)threadIdx.x) * R;
+    dict_rows<MODE, WORDS, UN, NT, R>(cur, row0, s_val, s_off, x, out, omega, dshift, [&] {
+      // rows past n (also every row of a tile past n_tiles) come back not live
+      dict_fetch<MODE, WORDS, NT, R>(nxt, (next * 256 + (int)threadIdx.x) * R,
+                                     next < n_tiles ? n : 0, codes, f, x, dshift);
+    });
+    cur = nxt;
+    tile = next;
+  }
+}
+
+static int dict_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+      cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+// resident workgroups per CU of one persistent instantiation (queried once)
+template <int MODE, int WORDS, int UN, bool NT, int R>
+static int dict_stream_occupancy() {
+  static int occ = 0;
+  if (occ == 0) {
+    int b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, dict_stream_kernel<MODE, WORDS, UN, NT, R>,
+                                                     256, 0) != hipSuccess || b < 1)
+      b = 2;
+    occ = b;
+  }
+  return occ;
+}
+
+template <int MODE, int WORDS, int UN>
+static hipError_t launch_dict_u(int64_t n, bool nt, const uint64_t* codes, const int32_t* doff,
+                                const double* dval, int ntab, const double* x, const double* f,
+                                double* out, double omega, int64_t dshift, hipStream_t st) {
+  // two rows per lane need 16-byte aligned f / out / codes (vector lane accesses)
+  const bool two = g_dict_rows_per_lane == 2 && n >= 4096 &&
+                   ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(out) |
+                     reinterpret_cast<uintptr_t>(codes)) & 15) == 0;
+  const int rr = two ? 2 : 1;
+  const int64_t tiles = (n + 256 * rr - 1) / (256 * rr);
+  // persistent + prefetch once every workgroup has several tiles to walk
+  // (never more workgroups than fit at once: a second round would start cold)
+#define AMG_DICT_GO(NTF, RR)                                                                       \
+  do {                                                                                             \
+    const int occ = dict_stream_occupancy<MODE, WORDS, UN, NTF, RR>();                             \
+    const int64_t resident =                                                                       \
+        g_dict_force_grid > 0                                                                      \
+            ? g_dict_force_grid                                                                    \
+            : (int64_t)dict_cu_count() * (occ < g_dict_blocks_per_cu ? occ : g_dict_blocks_per_cu); \
+    const bool persist = g_dict_force_grid > 0 || (g_dict_persistent != 0 && tiles >= 4 * resident); \
+    if (persist)                                                                                   \
+      hipLaunchKernelGGL((dict_stream_kernel<MODE, WORDS, UN, NTF, RR>), dim3((unsigned)resident),  \
+                         dim3(256), 0, st, (int)n, (int)tiles, codes, doff, dval, ntab, x, f, out, \
+                         omega, (int)dshift);                                                      \
+    else                                                                                           \
+      hipLaunchKernelGGL((dict_kernel<MODE, WORDS, UN, NTF, RR>), dim3((unsigned)tiles), dim3(256), \
+                         0, st, (int)n, codes, doff, dval, ntab, x, f, out, omega, (int)dshift,    \
+                         g_xcd_map);                                                               \
+  } while (0)
+  if (two) {
+    if (nt) AMG_DICT_GO(true, 2); else AMG_DICT_GO(false, 2);
+  } else {
+    if (nt) AMG_DICT_GO(true, 1); else AMG_DICT_GO(false, 1);
+  }
+#undef AMG_DICT_GO
+  return hipGetLastError();
+}
+template <int MODE>
+static hipError_t launch_dict_mode(int64_t n, int words, int wmax, bool nt, const uint64_t* codes,
+                                   const int32_t* doff, const double* dval, int ntab,
+                                   const double* x, const double* f, double* out, double omega,
+                                   int64_t dshift, hipStream_t st) {
+#define AMG_DICT(W, U) \
+  return launch_dict_u<MODE, W, U>(n, nt, codes, doff, dval, ntab, x, f, out, omega, dshift, st)
+  if (words == 1) {
+    if (wmax <= 3) AMG_DICT(1, 3);
+    if (wmax <= 5) AMG_DICT(1, 5);
+    if (wmax <= 7) AMG_DICT(1, 7);
+    AMG_DICT(1, 8);
+  }
+  if (wmax <= 9) AMG_DICT(2, 9);
+  if (wmax <= 12) AMG_DICT(2, 12);
+  AMG_DICT(2, 16);
+#undef AMG_DICT
+}
+void set_xcd_mapping(int on) { g_xcd_map = on ? 1 : 0; }
+void set_dict_rows_per_lane(int r) { g_dict_rows_per_lane = r == 1 ? 1 : 2; }
+void set_dict_persistent(int blocks_per_cu) {
+  g_dict_force_grid = blocks_per_cu < 0 ? -blocks_per_cu : 0;
+  g_dict_persistent = blocks_per_cu != 0;
+  if (blocks_per_cu > 0) g_dict_blocks_per_cu = blocks_per_cu > 16 ? 16 : blocks_per_cu;
+}
+hipError_t launch_dict(int mode, int64_t n, int words, int wmax, int nt, const uint64_t* codes,
+                       const int32_t* doff, const double* dval, int ntab, const double* x,
+                       const double* f, double* out, double omega, int64_t diag_shift,
+                       hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (n >= ((int64_t)1 << 31) - 256 || diag_shift >= ((int64_t)1 << 30) || ntab > 255 ||
+      (words != 1 && words != 2) || wmax > 8 * words)
+    return hipErrorInvalidValue;
+  switch (mode) {
+    case CSR_RESID: return launch_dict_mode<CSR_RESID>(n, words, wmax, nt != 0, codes, doff, dval, ntab, x, f, out, omega, diag_shift, st);
+    case CSR_JACOBI: return launch_dict_mode<CSR_JACOBI>(n, words, wmax, nt != 0, codes, doff, dval, ntab, x, f, out, omega, diag_shift, st);
+    case CSR_SPMV: return launch_dict_mode<CSR_SPMV>(n, words, wmax, nt != 0, codes, doff, dval, ntab, x, f, out, omega, diag_shift, st);
+    case CSR_RSSQ: return launch_dict_mode<CSR_RSSQ>(n, words, wmax, nt != 0, codes, doff, dval, ntab, x, f, out, omega, diag_shift, st);
+  }
+  return hipErrorInvalidValue;
+}
+
 // ------------------------------------------------- K-Restrict / K-ProlongAdd ---
 // f_H[j] = ((0 + 0.5 r[2j]) + 1.0 r[2j+1]) + 0.5 r[2j+2]   (Eigen column-major
 // scatter order of R*v, interpolator.hpp:64-68 with R = P^T, :132-134).

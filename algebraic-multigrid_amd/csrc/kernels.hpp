@@ -30,6 +30,14 @@ hipError_t launch_sell(int mode, int64_t n, int idx16, const int64_t* soff,
 // out = Jacobi sweep applied to (u + P uH), P = LinearInterpolator prolongation:
 // prolongation + add (multigrid.hpp:294-296) fused into the first post-smoothing
 // sweep; u itself is not modified.
+// K-Dict: dictionary-coded rows (host_setup.hpp: DictMat); modes as launch_sell.
+void set_xcd_mapping(int on);  // contiguous run of tiles per XCD (default on)
+void set_dict_rows_per_lane(int r);  // 1 or 2 (default), tuning / test switch
+void set_dict_persistent(int blocks_per_cu);  // 0: one tile per workgroup; k: k persistent workgroups per CU
+hipError_t launch_dict(int mode, int64_t n, int words, int wmax, int nt, const uint64_t* codes,
+                       const int32_t* doff, const double* dval, int ntab, const double* x,
+                       const double* f, double* out, double omega, int64_t diag_shift,
+                       hipStream_t st);
 hipError_t launch_sell_jacobi_prolong(int64_t n, int idx16, const int64_t* soff,
                                       const void* scol, const double* sval, const double* u,
                                       const double* uH, int64_t nH, const double* f, double* out,

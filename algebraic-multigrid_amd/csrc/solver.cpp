@@ -119,6 +119,10 @@ struct DevMat {
   int64_t slots = 0;
   int idx16 = 0;              // scol = int16 offsets from the diagonal column
   DevMem soff, scol, sval;
+  bool dict = false;          // K-Dict (dictionary-coded rows)
+  int dict_words = 0, dict_wmax = 0, dict_ntab = 0, dict_nt = 0;
+  int64_t dict_shift = 0;
+  DevMem dcodes, doff, dval;
 };
 
 int g_index16 = 1;  // use 16-bit relative column indices when a matrix allows it
@@ -170,6 +174,29 @@ hipError_t upload_mat(const Sparse& M, int layout, DevMat* D) {
 hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift, bool allow16) {
   D->n_rows = M.n_outer;
   D->nnz = M.nnz();
+  D->dict = false;
+  if ((layout == AMG_HIP_LAYOUT_AUTO || layout == AMG_HIP_LAYOUT_DICT) && allow16 &&
+      M.n_outer < ((int64_t)1 << 31) - 512) {
+    DictMat T;
+    if (to_dict(M, diag_shift, &T)) {
+      hipError_t e;
+      D->dict = true;
+      D->sell = false;
+      D->dict_words = T.words;
+      D->dict_wmax = T.max_width;
+      D->dict_ntab = (int)T.doff.size();
+      D->dict_shift = diag_shift;
+      // one sweep streams codes + f + out and gathers x: non-temporal stream when
+      // that is well beyond the 256 MiB Infinity Cache
+      const double stream_bytes = (double)M.n_outer * (8.0 * T.words + 24.0);
+      D->dict_nt = (g_nontemporal && stream_bytes > 192.0e6) ? 1 : 0;
+      if ((e = upload(D->dcodes, T.codes.data(), T.codes.size())) != hipSuccess) return e;
+      if ((e = upload(D->doff, T.doff.data(), T.doff.size())) != hipSuccess) return e;
+      return upload(D->dval, T.dval.data(), T.dval.size());
+    }
+    if (layout == AMG_HIP_LAYOUT_DICT) layout = AMG_HIP_LAYOUT_SELL;
+  }
+  if (layout == AMG_HIP_LAYOUT_DICT) layout = AMG_HIP_LAYOUT_SELL;
   bool sell = layout == AMG_HIP_LAYOUT_SELL;
   Sell64 S;
   if (layout != AMG_HIP_LAYOUT_CSR && M.n_outer < ((int64_t)1 << 31) - 512) {
@@ -216,6 +243,12 @@ hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift
 
 hipError_t launch_mat(int mode, const DevMat& A, const double* x, const double* f, double* out,
                       double omega, hipStream_t st, int64_t diag_shift = 0) {
+  if (A.dict) {
+    if (diag_shift != A.dict_shift) return hipErrorInvalidValue;  // offsets are baked in
+    return launch_dict(mode, A.n_rows, A.dict_words, A.dict_wmax, A.dict_nt,
+                       A.dcodes.as<uint64_t>(), A.doff.as<int32_t>(), A.dval.as<double>(),
+                       A.dict_ntab, x, f, out, omega, diag_shift, st);
+  }
   if (A.sell)
     return launch_sell(mode, A.n_rows, A.idx16, A.soff.as<int64_t>(), A.scol.p,
                        A.sval.as<double>(), x, f, out, omega, diag_shift, st);
@@ -555,7 +588,7 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
   if (s->opt.smoother < 0 || s->opt.smoother > AMG_HIP_SM_MULTICOLOR_GS)
     return fail(AMG_HIP_EINVAL, "unknown smoother kind");
   if (s->opt.smoother_iters < 0) return fail(AMG_HIP_EINVAL, "`smoother_iters` must be >= 0");
-  if (s->opt.layout < AMG_HIP_LAYOUT_AUTO || s->opt.layout > AMG_HIP_LAYOUT_SELL)
+  if (s->opt.layout < AMG_HIP_LAYOUT_AUTO || s->opt.layout > AMG_HIP_LAYOUT_DICT)
     return fail(AMG_HIP_EINVAL, "unknown matrix layout");
   if (s->opt.smoother == AMG_HIP_SM_SOR && (s->opt.omega > 2 || s->opt.omega < 0))
     return fail(AMG_HIP_EINVAL, "`omega` must be in [0, 2] but got omega=" +
@@ -754,9 +787,12 @@ void amg_hip_default_options(amg_hip_options* o) {
 
 void amg_hip_set_index16(int32_t on) { g_index16 = on ? 1 : 0; }
 void amg_hip_set_nontemporal(int32_t on) { g_nontemporal = on ? 1 : 0; }
+void amg_hip_set_xcd_mapping(int32_t on) { set_xcd_mapping(on); }
+void amg_hip_set_dict_rows(int32_t rows_per_lane) { set_dict_rows_per_lane(rows_per_lane); }
+void amg_hip_set_dict_persistent(int32_t blocks_per_cu) { set_dict_persistent(blocks_per_cu); }
 
 void amg_hip_set_default_layout(int32_t layout) {
-  if (layout >= AMG_HIP_LAYOUT_AUTO && layout <= AMG_HIP_LAYOUT_SELL) g_default_layout = layout;
+  if (layout >= AMG_HIP_LAYOUT_AUTO && layout <= AMG_HIP_LAYOUT_DICT) g_default_layout = layout;
 }
 
 int amg_hip_device_count(void) {
@@ -994,6 +1030,29 @@ amg_hip_status amg_hip_set_vec(amg_hip_solver* s, int32_t level, int32_t which,
   return AMG_HIP_OK;
 }
 int64_t amg_hip_coarse_halfbw(const amg_hip_solver* s) { return s ? s->band_w : -1; }
+
+amg_hip_status amg_hip_level_layout(const amg_hip_solver* s, int32_t level, int32_t* layout,
+                                    int64_t* matrix_stream_bytes) {
+  if (!s || level < 0 || level >= (int32_t)s->lv.size())
+    return fail(AMG_HIP_EINVAL, "level out of range");
+  if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "host_only solver has no device matrices");
+  const DevMat& A = s->lv[level].A_rows;
+  int32_t lay;
+  int64_t bytes;
+  if (A.dict) {
+    lay = AMG_HIP_LAYOUT_DICT;
+    bytes = A.n_rows * 8 * A.dict_words + (int64_t)A.dict_ntab * 12;
+  } else if (A.sell) {
+    lay = AMG_HIP_LAYOUT_SELL;
+    bytes = A.slots * ((A.idx16 & 1) ? 10 : 12) + (A.n_rows + 63) / 64 * 8;
+  } else {
+    lay = AMG_HIP_LAYOUT_CSR;
+    bytes = A.csr.nnz * 12 + (A.csr.n_rows + 1) * 4;
+  }
+  if (layout) *layout = lay;
+  if (matrix_stream_bytes) *matrix_stream_bytes = bytes;
+  return AMG_HIP_OK;
+}
 
 amg_hip_status amg_hip_get_colors(const amg_hip_solver* s, int32_t level, int32_t* color,
                                   int32_t* n_colors) {

@@ -71,6 +71,11 @@ def run_single(args):
         raise SystemExit("bench.py needs a HIP device (libamg_hip.so has no CPU fallback)")
     if args.no_nt:
         amg.lib().amg_hip_set_nontemporal(0)
+    amg.set_dict_rows(args.dict_rows)
+    amg.set_xcd_mapping(not args.no_xcd_map)
+    amg.set_dict_persistent(args.dict_persistent)
+    amg.set_default_layout({"auto": amg.LAYOUT_AUTO, "csr": amg.LAYOUT_CSR, "sell": amg.LAYOUT_SELL,
+                            "dict": amg.LAYOUT_DICT}[args.layout])
     t0 = time.time()
     colptr, rowind, val = amg.laplacian(args.n)
     b = amg.rhs(args.n)
@@ -102,15 +107,24 @@ def run_single(args):
         raise SystemExit(f"V-cycle iteration is not converging (rss {rss0:.3e} -> {rss:.3e})")
     sizes = [mg.get_n_dofs(l) for l in range(L)]
     achieved = sweep_bytes / (avg_ms * 1e-3) / 1e9
+    lay, mat_bytes = mg.level_layout(0)
+    lay_name = {amg.LAYOUT_CSR: "csr", amg.LAYOUT_SELL: "sell", amg.LAYOUT_DICT: "dict"}[lay]
+    # what the format has to move per sweep: matrix stream + f + x + out (8 B each per row)
+    format_bytes = mat_bytes + 24 * sizes[0]
+    kernel = {"dict": ("dict_kernel<CSR_JACOBI, 1 word, 5 entries, nt> (level-0 Jacobi sweep, "
+                       "dictionary-coded rows)", "r01d_pmc_traffic", "dict_kernel<1, 1, 5, true>@16777216"),
+              "sell": ("sell_kernel<CSR_JACOBI, idx16, nt> (level-0 Jacobi sweep, SELL-64 panels)",
+                       "r01c_pmc_traffic", "sell_kernel<1, true, true>@16777216"),
+              "csr": ("csr_stage_kernel<CSR_JACOBI> (level-0 Jacobi sweep, LDS-staged CSR)", None, None)}[lay_name]
     # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run
     # inside this process); only quoted for the configuration it was measured on.
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
-    if os.path.exists(pmc) and args.n == 4096:
+    pmc = os.path.join(ROOT, "profiles", f"{kernel[1]}.json")
+    if kernel[1] and os.path.exists(pmc) and args.n == 4096 and not args.no_nt:
         rec = json.load(open(pmc))
-        k = rec["kernels"].get("sell_kernel<1, true, true>@16777216")
+        k = rec["kernels"].get(kernel[2])
         if k and rec.get("n") == args.n:
-            traffic, traffic_src = k["traffic_bytes"], "profiles/r01c_pmc_traffic.md: " + rec["source"]
+            traffic, traffic_src = k["traffic_bytes"], f"profiles/{kernel[1]}.md: " + rec["source"]
     out = {
         "metric": "V-cycles/sec, 2D Poisson N=4096^2 (fine-grid smoother HBM GB/s under roofline)",
         "value": args.steps / dt,
@@ -135,7 +149,7 @@ def run_single(args):
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "sell_kernel<CSR_JACOBI, idx16, nt> (level-0 Jacobi sweep, SELL-64 panels)",
+            "kernel": kernel[0],
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -143,6 +157,9 @@ def run_single(args):
             "traffic": traffic,
             "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": sweep_bytes,
+            "layout": lay_name,
+            "format_bytes_per_launch": format_bytes,
+            "format_GBps": format_bytes / (avg_ms * 1e-3) / 1e9,
             "avg_launch_ms": avg_ms,
             "min_launch_ms": min_ms,
             "launches_timed": args.profile_launches,
@@ -167,7 +184,14 @@ def main():
     ap.add_argument("--sweeps", type=int, default=2, help="Jacobi sweeps per smooth() call")
     ap.add_argument("--smoother", choices=["jacobi", "multicolor"], default="jacobi")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--layout", choices=["auto", "csr", "sell", "dict"], default="auto",
+                    help="device layout of the level matrices (auto: dictionary-coded rows where a "
+                         "matrix qualifies, else SELL-64)")
     ap.add_argument("--no-nt", action="store_true", help="disable the non-temporal matrix stream")
+    ap.add_argument("--no-xcd-map", action="store_true", help="K-Dict: plain blockIdx -> tile mapping")
+    ap.add_argument("--dict-rows", type=int, default=2, choices=[1, 2], help="K-Dict rows per lane")
+    ap.add_argument("--dict-persistent", type=int, default=0,
+                    help="K-Dict persistent workgroups per CU on large levels (0 = one tile per workgroup)")
     ap.add_argument("--fast-coarse", action="store_true",
                     help="partitioned (parallel) coarse solve; then fewer levels pay off (--levels 13)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

@@ -54,11 +54,16 @@ typedef enum {
   AMG_HIP_SM_MULTICOLOR_GS = 4  /* symmetric multicolour Gauss-Seidel           */
 } amg_hip_smoother;
 
-/* Device layout of the level matrices (results are bit-identical in both).   */
+/* Device layout of the level matrices (results are bit-identical in all).    */
 typedef enum {
-  AMG_HIP_LAYOUT_AUTO = 0, /* SELL-64 unless its padding exceeds 25 %            */
+  AMG_HIP_LAYOUT_AUTO = 0, /* DICT when the matrix qualifies, else SELL-64 unless
+                              its padding exceeds 25 %, else CSR                 */
   AMG_HIP_LAYOUT_CSR = 1,  /* plain CSR, LDS-staged kernel (K-CSR)               */
-  AMG_HIP_LAYOUT_SELL = 2  /* CSR sliced in 64-row lane-interleaved panels       */
+  AMG_HIP_LAYOUT_SELL = 2, /* CSR sliced in 64-row lane-interleaved panels       */
+  AMG_HIP_LAYOUT_DICT = 3  /* dictionary-coded rows (K-Dict): one byte per entry
+                              indexing a table of the matrix's distinct
+                              (column offset, value) pairs; needs <= 255 pairs
+                              and rows of <= 16 entries, else falls back to SELL */
 } amg_hip_layout;
 
 /* Options of amg_hip_create.  Zero-initialise, then amg_hip_default_options. */
@@ -116,6 +121,17 @@ void amg_hip_set_index16(int32_t on);
 /* Stream matrices larger than ~192 MB with non-temporal loads (process-wide, default
  * on): the once-read matrix then does not evict the x lines the gathers re-use.  */
 void amg_hip_set_nontemporal(int32_t on);
+/* K-Dict: give every XCD one contiguous run of row tiles, so that the +-bandwidth
+ * re-reads of x hit the L2 that fetched them (default on).  Tuning switch.       */
+void amg_hip_set_xcd_mapping(int32_t on);
+/* K-Dict rows per lane: 2 (default; 16-byte lane accesses) or 1.  Process-wide;
+ * bit-identical results, a tuning / test switch.                                */
+void amg_hip_set_dict_rows(int32_t rows_per_lane);
+/* K-Dict on large levels: k > 0 persistent workgroups per CU that prefetch their
+ * next tile (at most k, never more than fit at once); 0 = one tile per workgroup
+ * (default: measured as fast); k < 0 = always persistent with |k| workgroups in total (test
+ * hook: small matrices then walk many tiles per workgroup).                      */
+void amg_hip_set_dict_persistent(int32_t blocks_per_cu);
 
 /* Number of usable HIP devices (0 when none; never fails). */
 int amg_hip_device_count(void);
@@ -201,6 +217,13 @@ amg_hip_status amg_hip_copy_vec_dev(amg_hip_solver* s, int32_t level, int32_t wh
                                     void* dev_ptr, int32_t to_solver);
 /* Zero-fill a level vector on the solver's stream. */
 amg_hip_status amg_hip_zero_vec(amg_hip_solver* s, int32_t level, int32_t which);
+
+/* Device layout the level's operator was uploaded in (amg_hip_layout, never AUTO)
+ * and the bytes of its matrix stream (indices + values, or codes + table) that
+ * one sweep reads -- what the format actually moves, next to the CSR-formula
+ * figure of amg_hip_cycle_bytes.  host_only solvers: EINVAL.                    */
+amg_hip_status amg_hip_level_layout(const amg_hip_solver* s, int32_t level, int32_t* layout,
+                                    int64_t* matrix_stream_bytes);
 
 /* Half-bandwidth of the factored coarsest operator. */
 int64_t amg_hip_coarse_halfbw(const amg_hip_solver* s);

@@ -47,13 +47,13 @@ def big(amg):
 
 
 def test_4096_layouts_agree_bitwise_and_rss_decreases(amg, big):
-    """BASELINE config 3 (4096^2, true Jacobi): the SELL-64 and the LDS-staged CSR
-    kernels give the same bits over whole V-cycles; rss decreases monotonically
+    """BASELINE config 3 (4096^2, true Jacobi): the dictionary-coded, the SELL-64 and
+    the LDS-staged CSR kernels give the same bits over whole V-cycles; rss decreases monotonically
     after the first cycle; level sizes follow n_H = (n_h+1)/2 - 1."""
     n, cp, ri, v, b = big
     L = 16
     out = {}
-    for lay in (amg.LAYOUT_SELL, amg.LAYOUT_CSR):
+    for lay in (amg.LAYOUT_SELL, amg.LAYOUT_CSR, amg.LAYOUT_DICT):
         mg = amg.Multigrid(cp, ri, v, b, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6, layout=lay)
         if lay == amg.LAYOUT_SELL:
             sizes = [mg.get_n_dofs(l) for l in range(L)]
@@ -68,8 +68,9 @@ def test_4096_layouts_agree_bitwise_and_rss_decreases(amg, big):
         assert all(rss[i + 1] < rss[i] for i in range(len(rss) - 1)), rss
         out[lay] = (mg.get_soln(0), rss)
         mg.close()
-    assert np.array_equal(out[amg.LAYOUT_SELL][0], out[amg.LAYOUT_CSR][0])
-    assert out[amg.LAYOUT_SELL][1] == out[amg.LAYOUT_CSR][1]
+    for lay in (amg.LAYOUT_CSR, amg.LAYOUT_DICT):
+        assert np.array_equal(out[amg.LAYOUT_SELL][0], out[lay][0])
+        assert out[amg.LAYOUT_SELL][1] == out[lay][1]
 
 
 def test_4096_residual_is_affine_and_exact_on_quadratics(amg, big):
