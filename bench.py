@@ -111,8 +111,8 @@ def run_single(args):
     lay_name = {amg.LAYOUT_CSR: "csr", amg.LAYOUT_SELL: "sell", amg.LAYOUT_DICT: "dict"}[lay]
     # what the format has to move per sweep: matrix stream + f + x + out (8 B each per row)
     format_bytes = mat_bytes + 24 * sizes[0]
-    kernel = {"dict": ("dict_kernel<CSR_JACOBI, 1 word, 5 entries, nt> (level-0 Jacobi sweep, "
-                       "dictionary-coded rows)", "r01d_pmc_traffic", "dict_kernel<1, 1, 5, true>@16777216"),
+    kernel = {"dict": ("dict_kernel<CSR_JACOBI, 1 code word, 5 entries, nt, 2 rows/lane> (level-0 Jacobi sweep, "
+                       "dictionary-coded rows)", "r01d_pmc_traffic", "dict_kernel<1, 1, 5, true, 2>@16777216"),
               "sell": ("sell_kernel<CSR_JACOBI, idx16, nt> (level-0 Jacobi sweep, SELL-64 panels)",
                        "r01c_pmc_traffic", "sell_kernel<1, true, true>@16777216"),
               "csr": ("csr_stage_kernel<CSR_JACOBI> (level-0 Jacobi sweep, LDS-staged CSR)", None, None)}[lay_name]
@@ -160,6 +160,12 @@ def run_single(args):
             "layout": lay_name,
             "format_bytes_per_launch": format_bytes,
             "format_GBps": format_bytes / (avg_ms * 1e-3) / 1e9,
+            "hbm_GBps_measured": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+            "hbm_frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "note": ("achieved/frac use the CSR-formula bytes of SURVEY 8(d) (12 nnz + 28 n per sweep), i.e. "
+                     "the CSR-equivalent rate; the dictionary-coded layout moves format_bytes_per_launch "
+                     "(8 B of codes + f + x + out per row), so frac can exceed 1 -- hbm_*_measured is the "
+                     "PMC traffic over the same launch time against the 8 TB/s peak") if lay_name == "dict" else None,
             "avg_launch_ms": avg_ms,
             "min_launch_ms": min_ms,
             "launches_timed": args.profile_launches,
