@@ -131,7 +131,6 @@ _SIGS = {
     "amg_hip_set_nontemporal": (None, [C.c_int32]),
     "amg_hip_set_dict_rows": (None, [C.c_int32]),
     "amg_hip_set_xcd_mapping": (None, [C.c_int32]),
-    "amg_hip_set_dict_persistent": (None, [C.c_int32]),
     "amg_hip_devmat_destroy": (None, [C.c_void_p]),
     "amg_hip_devmat_apply": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_double, C.c_int64, C.c_void_p]),
@@ -216,10 +215,6 @@ def set_dict_rows(rows_per_lane):
 
 def set_xcd_mapping(on):
     lib().amg_hip_set_xcd_mapping(int(on))
-
-
-def set_dict_persistent(blocks_per_cu):
-    lib().amg_hip_set_dict_persistent(int(blocks_per_cu))
 
 
 # ---- Grid<double> ------------------------------------------------------------

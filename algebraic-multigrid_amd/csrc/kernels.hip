@@ -397,9 +397,6 @@ hipError_t launch_sell_gs_color(int64_t n_storage, int /*idx16: rows are permute
 
 static int g_dict_rows_per_lane = 2;
 static int g_xcd_map = 1;
-static int g_dict_persistent = 0;  // measured no faster than one tile per workgroup
-static int g_dict_blocks_per_cu = 8;
-static int g_dict_force_grid = 0;  // test hook: > 0 = always persistent with this many workgroups
 // ---------------------------------------------------------------- K-Dict -----
 // The same four operations on a dictionary-coded matrix (host_setup.hpp: DictMat).
 // Lane per row; the row's structure is ONE 8- or 16-byte load (byte j = code of
@@ -411,10 +408,8 @@ static int g_dict_force_grid = 0;  // test hook: > 0 = always persistent with th
 // R = rows per lane (1 or 2).  R = 2: a lane owns rows 2t and 2t+1, so codes, f and
 // the output move as 16-byte (32-byte for two-word codes) lane accesses and twice as
 // many bytes are in flight per wave (the launcher checks the 16-byte alignment).
-// A row's work is two dependent memory round trips (codes -> table -> x gathers), so
-// large levels run PERSISTENT workgroups that fetch the streamed operands of their
-// next tile before they wait for the gathers of the current one; the table is staged
-// once per workgroup.
+// (Persistent workgroups that prefetch their next tile were measured 10 % SLOWER on the
+// 4096^2 fine level, 108 vs 99 us, and are not kept.)
 template <int WORDS, int R>
 struct DictStream {  // streamed operands of R rows of one lane
   uint64_t cw[R][2];
@@ -462,14 +457,12 @@ __device__ __forceinline__ void dict_fetch(DictStream<WORDS, R>& s, int row0, in
     if (MODE == CSR_JACOBI) s.xi[0] = x[row0 + dshift];
   }
 }
-// decode + gather + row arithmetic + store of one tile; `between` runs after the
-// gathers are issued and before their results are used (the next tile's fetch)
-template <int MODE, int WORDS, int UN, bool NT, int R, class Between>
+// decode + gather + row arithmetic of the R rows of one lane
+template <int MODE, int WORDS, int UN, int R>
 __device__ __forceinline__ void dict_rows(const DictStream<WORDS, R>& s, int row0,
                                           const double* s_val, const int32_t* s_off,
-                                          const double* x, double* out, double omega, int dshift,
-                                          Between between) {
-  typedef double f64x2 __attribute__((ext_vector_type(2)));
+                                          const double* x, double omega, int dshift,
+                                          double (&res)[R]) {
   int c[R][UN];
   double v[R][UN], xx[R][UN];
   bool ok[R][UN];
@@ -489,8 +482,6 @@ __device__ __forceinline__ void dict_rows(const DictStream<WORDS, R>& s, int row
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int u = 0; u < UN; ++u) xx[r][u] = x[c[r][u]];
-  between();
-  double res[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int drow = s.live[r] ? row0 + r + dshift : 0;
@@ -518,6 +509,11 @@ __device__ __forceinline__ void dict_rows(const DictStream<WORDS, R>& s, int row
       res[r] = d * d;
     }
   }
+}
+template <int WORDS, bool NT, int R>
+__device__ __forceinline__ void dict_store(const DictStream<WORDS, R>& s, int row0,
+                                           const double (&res)[R], double* out) {
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
   if (R == 2 && s.live[R - 1]) {
     f64x2 t;
     t.x = res[0]; t.y = res[R - 1];
@@ -554,62 +550,113 @@ __global__ __launch_bounds__(256) void dict_kernel(
     s_off[threadIdx.x] = doff[threadIdx.x];
   }
   __syncthreads();
-  dict_rows<MODE, WORDS, UN, NT, R>(s, row0, s_val, s_off, x, out, omega, dshift, [] {});
+  double res[R];
+  dict_rows<MODE, WORDS, UN, R>(s, row0, s_val, s_off, x, omega, dshift, res);
+  dict_store<WORDS, NT, R>(s, row0, res, out);
 }
 
-// persistent form: workgroup b walks tiles b, b + gridDim.x, ...
-template <int MODE, int WORDS, int UN, bool NT, int R>
-__global__ __launch_bounds__(256) void dict_stream_kernel(
-    int n, int n_tiles, const uint64_t* __restrict__ codes, const int32_t* __restrict__ doff,
+// ---- fused forms for the true-Jacobi V-cycle on linear-interpolation levels --------
+// Tiles of 256 R rows that OVERLAP by two rows (stride 256 R - 2): the row results of
+// a tile are parked in LDS, and everything a coarse point j needs from the fine rows
+// 2j, 2j+1, 2j+2 (restriction) or from its neighbour j-1 (prolongation) is then inside
+// one tile.  The two duplicated rows are recomputed (0.4 %) and stored twice with the
+// same bits.  Same per-row arithmetic and the same transfer expressions as the
+// separate kernels, so the V-cycle is bit-identical with and without these fusions.
+//
+// (1) residual + restriction + first coarse Jacobi sweep (multigrid.hpp:272-282, then
+// :268 on level l+1 whose u is zero): r = f - A u is written, f_H = R r is written, and
+// the from-zero sweep of the coarse level (jacobi_from_zero_kernel) is written to uH1.
+template <int WORDS, int UN, bool NT, int R>
+__global__ __launch_bounds__(256) void dict_resid_restrict_kernel(
+    int n, const uint64_t* __restrict__ codes, const int32_t* __restrict__ doff,
     const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
-    double* out, double omega, int dshift) {
+    double* r_out, int nH, double* __restrict__ fH, const double* __restrict__ diagH,
+    double* __restrict__ uH1, double omega, int xcd_map) {
   __shared__ double s_val[256];
   __shared__ int32_t s_off[256];
-  int tile = blockIdx.x;
-  DictStream<WORDS, R> cur, nxt;
-  dict_fetch<MODE, WORDS, NT, R>(cur, (tile * 256 + (int)threadIdx.x) * R, n, codes, f, x, dshift);
+  __shared__ double rs[256 * R];
+  const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
+  const int row0 = tile * (256 * R - 2) + (int)threadIdx.x * R;
+  DictStream<WORDS, R> s;
+  dict_fetch<CSR_RESID, WORDS, NT, R>(s, row0, n, codes, f, x, 0);
   if ((int)threadIdx.x < ntab) {
     s_val[threadIdx.x] = dval[threadIdx.x];
     s_off[threadIdx.x] = doff[threadIdx.x];
   }
   __syncthreads();
-  while (tile < n_tiles) {  // uniform per workgroup, bounded
-    const int next = tile + (int)gridDim.x;
-    const int row0 = (tile * 256 + (int)threadIdx.x) * R;
-    dict_rows<MODE, WORDS, UN, NT, R>(cur, row0, s_val, s_off, x, out, omega, dshift, [&] {
-      // rows past n (also every row of a tile past n_tiles) come back not live
-      dict_fetch<MODE, WORDS, NT, R>(nxt, (next * 256 + (int)threadIdx.x) * R,
-                                     next < n_tiles ? n : 0, codes, f, x, dshift);
-    });
-    cur = nxt;
-    tile = next;
+  double res[R];
+  dict_rows<CSR_RESID, WORDS, UN, R>(s, row0, s_val, s_off, x, omega, 0, res);
+  dict_store<WORDS, NT, R>(s, row0, res, r_out);
+#pragma unroll
+  for (int r = 0; r < R; ++r) rs[threadIdx.x * R + r] = s.live[r] ? res[r] : 0.0;
+  __syncthreads();
+  for (int q = threadIdx.x; q < 128 * R - 1; q += 256) {
+    const int j = tile * (128 * R - 1) + q;
+    if (j >= nH) break;
+    const int64_t i = 2 * (int64_t)j;  // linear_restrict_kernel, same guards and order
+    double sum = 0.0;
+    if (i < n) sum += 0.5 * rs[2 * q];
+    if (i + 1 < n) sum += 1.0 * rs[2 * q + 1];
+    if (i + 2 < n) sum += 0.5 * rs[2 * q + 2];
+    fH[j] = sum;
+    const double xi = 0.0, acc = 0.0;  // jacobi_from_zero_kernel
+    const double d = diagH[j];
+    uH1[j] = (d == 0.0) ? xi : xi + omega * ((sum - acc) / d - xi);
   }
 }
-
-static int dict_cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-      cus = p.multiProcessorCount;
-    if (cus <= 0) cus = 256;
+// (2) Jacobi sweep on level H + prolongation of its result into the finer level
+// (multigrid.hpp:300 on level l+1, then :294-296 on level l):
+// u_h[2j] += 0.5 u_H[j-1] + 0.5 u_H[j], u_h[2j+1] += u_H[j] (linear_prolong_add2_kernel).
+template <int WORDS, int UN, bool NT, int R>
+__global__ __launch_bounds__(256) void dict_jacobi_prolong_kernel(
+    int n, const uint64_t* __restrict__ codes, const int32_t* __restrict__ doff,
+    const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
+    double* out, double omega, int n_h, double* uh, int xcd_map) {
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  __shared__ double s_val[256];
+  __shared__ int32_t s_off[256];
+  __shared__ double rs[256 * R];
+  const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
+  const int stride = 256 * R - 2;
+  const int row0 = tile * stride + (int)threadIdx.x * R;
+  DictStream<WORDS, R> s;
+  dict_fetch<CSR_JACOBI, WORDS, NT, R>(s, row0, n, codes, f, x, 0);
+  if ((int)threadIdx.x < ntab) {
+    s_val[threadIdx.x] = dval[threadIdx.x];
+    s_off[threadIdx.x] = doff[threadIdx.x];
   }
-  return cus;
-}
-
-// resident workgroups per CU of one persistent instantiation (queried once)
-template <int MODE, int WORDS, int UN, bool NT, int R>
-static int dict_stream_occupancy() {
-  static int occ = 0;
-  if (occ == 0) {
-    int b = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, dict_stream_kernel<MODE, WORDS, UN, NT, R>,
-                                                     256, 0) != hipSuccess || b < 1)
-      b = 2;
-    occ = b;
+  __syncthreads();
+  double res[R];
+  dict_rows<CSR_JACOBI, WORDS, UN, R>(s, row0, s_val, s_off, x, omega, 0, res);
+  dict_store<WORDS, NT, R>(s, row0, res, out);
+#pragma unroll
+  for (int r = 0; r < R; ++r) rs[threadIdx.x * R + r] = s.live[r] ? res[r] : 0.0;
+  __syncthreads();
+  // this tile prolongs the coarse points q = 1 .. stride (q = 0 too in the first tile);
+  // j = n is the virtual point whose fine rows only receive the left neighbour / + 0.0
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int q = (int)threadIdx.x * R + r;
+    const int j = tile * stride + q;
+    if ((q == 0 && tile != 0) || q > stride || j > n) continue;
+    double t0 = 0.0, t1 = 0.0;
+    const double b = (j < n) ? rs[q] : 0.0;
+    if (j >= 1 && j - 1 < n) t0 += 0.5 * rs[q - 1];
+    if (j < n) {
+      t0 += 0.5 * b;
+      t1 += 1.0 * b;
+    }
+    const int64_t i = 2 * (int64_t)j;
+    if (i + 1 < n_h) {
+      f64x2* up = reinterpret_cast<f64x2*>(uh + i);
+      f64x2 u = *up;
+      u.x = u.x + t0;
+      u.y = u.y + t1;
+      *up = u;
+    } else if (i < n_h) {
+      uh[i] = uh[i] + t0;
+    }
   }
-  return occ;
 }
 
 template <int MODE, int WORDS, int UN>
@@ -622,25 +669,9 @@ static hipError_t launch_dict_u(int64_t n, bool nt, const uint64_t* codes, const
                      reinterpret_cast<uintptr_t>(codes)) & 15) == 0;
   const int rr = two ? 2 : 1;
   const int64_t tiles = (n + 256 * rr - 1) / (256 * rr);
-  // persistent + prefetch once every workgroup has several tiles to walk
-  // (never more workgroups than fit at once: a second round would start cold)
-#define AMG_DICT_GO(NTF, RR)                                                                       \
-  do {                                                                                             \
-    const int occ = dict_stream_occupancy<MODE, WORDS, UN, NTF, RR>();                             \
-    const int64_t resident =                                                                       \
-        g_dict_force_grid > 0                                                                      \
-            ? g_dict_force_grid                                                                    \
-            : (int64_t)dict_cu_count() * (occ < g_dict_blocks_per_cu ? occ : g_dict_blocks_per_cu); \
-    const bool persist = g_dict_force_grid > 0 || (g_dict_persistent != 0 && tiles >= 4 * resident); \
-    if (persist)                                                                                   \
-      hipLaunchKernelGGL((dict_stream_kernel<MODE, WORDS, UN, NTF, RR>), dim3((unsigned)resident),  \
-                         dim3(256), 0, st, (int)n, (int)tiles, codes, doff, dval, ntab, x, f, out, \
-                         omega, (int)dshift);                                                      \
-    else                                                                                           \
-      hipLaunchKernelGGL((dict_kernel<MODE, WORDS, UN, NTF, RR>), dim3((unsigned)tiles), dim3(256), \
-                         0, st, (int)n, codes, doff, dval, ntab, x, f, out, omega, (int)dshift,    \
-                         g_xcd_map);                                                               \
-  } while (0)
+#define AMG_DICT_GO(NTF, RR)                                                                     \
+  hipLaunchKernelGGL((dict_kernel<MODE, WORDS, UN, NTF, RR>), dim3((unsigned)tiles), dim3(256), 0, \
+                     st, (int)n, codes, doff, dval, ntab, x, f, out, omega, (int)dshift, g_xcd_map)
   if (two) {
     if (nt) AMG_DICT_GO(true, 2); else AMG_DICT_GO(false, 2);
   } else {
@@ -667,13 +698,79 @@ static hipError_t launch_dict_mode(int64_t n, int words, int wmax, bool nt, cons
   AMG_DICT(2, 16);
 #undef AMG_DICT
 }
+// (W, U) dispatch shared by the fused launchers: F is a generic lambda taking
+// std::integral_constant<int, W>, <int, U>, <bool, NT>, <int, R>
+template <class F>
+static hipError_t dict_dispatch(int words, int wmax, bool nt, bool two, F&& go) {
+  using std::integral_constant;
+  auto with_nr = [&](auto W, auto U) -> hipError_t {
+    if (two) {
+      if (nt) go(W, U, integral_constant<bool, true>{}, integral_constant<int, 2>{});
+      else go(W, U, integral_constant<bool, false>{}, integral_constant<int, 2>{});
+    } else {
+      if (nt) go(W, U, integral_constant<bool, true>{}, integral_constant<int, 1>{});
+      else go(W, U, integral_constant<bool, false>{}, integral_constant<int, 1>{});
+    }
+    return hipGetLastError();
+  };
+  if (words == 1) {
+    if (wmax <= 3) return with_nr(integral_constant<int, 1>{}, integral_constant<int, 3>{});
+    if (wmax <= 5) return with_nr(integral_constant<int, 1>{}, integral_constant<int, 5>{});
+    if (wmax <= 7) return with_nr(integral_constant<int, 1>{}, integral_constant<int, 7>{});
+    return with_nr(integral_constant<int, 1>{}, integral_constant<int, 8>{});
+  }
+  if (wmax <= 9) return with_nr(integral_constant<int, 2>{}, integral_constant<int, 9>{});
+  if (wmax <= 12) return with_nr(integral_constant<int, 2>{}, integral_constant<int, 12>{});
+  return with_nr(integral_constant<int, 2>{}, integral_constant<int, 16>{});
+}
+static bool dict_args_ok(int64_t n, int words, int wmax, int ntab) {
+  return n < ((int64_t)1 << 31) - 1024 && ntab <= 255 && (words == 1 || words == 2) &&
+         wmax <= 8 * words;
+}
+static bool aligned16(const void* a, const void* b, const void* c) {
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
+           reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+hipError_t launch_dict_resid_restrict(int64_t n, int words, int wmax, int nt,
+                                      const uint64_t* codes, const int32_t* doff,
+                                      const double* dval, int ntab, const double* x,
+                                      const double* f, double* r_out, int64_t nH, double* fH,
+                                      const double* diagH, double* uH1, double omega,
+                                      hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (!dict_args_ok(n, words, wmax, ntab) || nH > n || !fH || !diagH || !uH1)
+    return hipErrorInvalidValue;
+  const bool two = g_dict_rows_per_lane == 2 && n >= 4096 && aligned16(f, r_out, codes);
+  const int64_t stride = 256 * (two ? 2 : 1) - 2;
+  const unsigned tiles = (unsigned)((n + stride - 1) / stride);
+  return dict_dispatch(words, wmax, nt != 0, two, [&](auto W, auto U, auto NTF, auto RR) {
+    hipLaunchKernelGGL((dict_resid_restrict_kernel<decltype(W)::value, decltype(U)::value,
+                                                   decltype(NTF)::value, decltype(RR)::value>),
+                       dim3(tiles), dim3(256), 0, st, (int)n, codes, doff, dval, ntab, x, f, r_out,
+                       (int)nH, fH, diagH, uH1, omega, g_xcd_map);
+  });
+}
+hipError_t launch_dict_jacobi_prolong(int64_t n, int words, int wmax, int nt,
+                                      const uint64_t* codes, const int32_t* doff,
+                                      const double* dval, int ntab, const double* x,
+                                      const double* f, double* out, double omega, int64_t n_h,
+                                      double* uh, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (!dict_args_ok(n_h, words, wmax, ntab) || n > n_h || !uh ||
+      (reinterpret_cast<uintptr_t>(uh) & 15) != 0)
+    return hipErrorInvalidValue;
+  const bool two = g_dict_rows_per_lane == 2 && n >= 4096 && aligned16(f, out, codes);
+  const int64_t stride = 256 * (two ? 2 : 1) - 2;
+  const unsigned tiles = (unsigned)((n + stride - 1) / stride);
+  return dict_dispatch(words, wmax, nt != 0, two, [&](auto W, auto U, auto NTF, auto RR) {
+    hipLaunchKernelGGL((dict_jacobi_prolong_kernel<decltype(W)::value, decltype(U)::value,
+                                                   decltype(NTF)::value, decltype(RR)::value>),
+                       dim3(tiles), dim3(256), 0, st, (int)n, codes, doff, dval, ntab, x, f, out,
+                       omega, (int)n_h, uh, g_xcd_map);
+  });
+}
 void set_xcd_mapping(int on) { g_xcd_map = on ? 1 : 0; }
 void set_dict_rows_per_lane(int r) { g_dict_rows_per_lane = r == 1 ? 1 : 2; }
-void set_dict_persistent(int blocks_per_cu) {
-  g_dict_force_grid = blocks_per_cu < 0 ? -blocks_per_cu : 0;
-  g_dict_persistent = blocks_per_cu != 0;
-  if (blocks_per_cu > 0) g_dict_blocks_per_cu = blocks_per_cu > 16 ? 16 : blocks_per_cu;
-}
 hipError_t launch_dict(int mode, int64_t n, int words, int wmax, int nt, const uint64_t* codes,
                        const int32_t* doff, const double* dval, int ntab, const double* x,
                        const double* f, double* out, double omega, int64_t diag_shift,

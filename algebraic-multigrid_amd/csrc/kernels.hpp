@@ -33,7 +33,20 @@ hipError_t launch_sell(int mode, int64_t n, int idx16, const int64_t* soff,
 // K-Dict: dictionary-coded rows (host_setup.hpp: DictMat); modes as launch_sell.
 void set_xcd_mapping(int on);  // contiguous run of tiles per XCD (default on)
 void set_dict_rows_per_lane(int r);  // 1 or 2 (default), tuning / test switch
-void set_dict_persistent(int blocks_per_cu);  // 0: one tile per workgroup; k: k persistent workgroups per CU
+// fused forms for the true-Jacobi V-cycle on linear-interpolation levels (kernels.hip):
+// r = f - A x (written), f_H = R r, uH1 = first Jacobi sweep of the coarse level from zero
+hipError_t launch_dict_resid_restrict(int64_t n, int words, int wmax, int nt,
+                                      const uint64_t* codes, const int32_t* doff,
+                                      const double* dval, int ntab, const double* x,
+                                      const double* f, double* r_out, int64_t nH, double* fH,
+                                      const double* diagH, double* uH1, double omega,
+                                      hipStream_t st);
+// out = Jacobi sweep of x on this (coarse) level, then uh += P out on the finer level
+hipError_t launch_dict_jacobi_prolong(int64_t n, int words, int wmax, int nt,
+                                      const uint64_t* codes, const int32_t* doff,
+                                      const double* dval, int ntab, const double* x,
+                                      const double* f, double* out, double omega, int64_t n_h,
+                                      double* uh, hipStream_t st);
 hipError_t launch_dict(int mode, int64_t n, int words, int wmax, int nt, const uint64_t* codes,
                        const int32_t* doff, const double* dval, int ntab, const double* x,
                        const double* f, double* out, double omega, int64_t diag_shift,

@@ -381,7 +381,27 @@ bool jacobi_fuses_prolong(const amg_hip_solver* s, int l) {
          L.A_cols().sell;
 }
 
-amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0) {
+// Fusions of the true-Jacobi V-cycle across a level boundary (kernels.hip, "fused
+// forms"): both need the dictionary-coded layout and the matrix-free linear transfers.
+// down: residual of level l + restriction + first (from-zero) sweep of level l+1
+bool fuses_resid_restrict(const amg_hip_solver* s, int l) {
+  if (l + 1 >= (int)s->lv.size()) return false;
+  const Level& L = s->lv[l];
+  return jacobi_fuses_zero(s) && L.linear && s->opt.stencil_transfers && L.A_rows.dict &&
+         L.A_rows.dict_shift == 0 && s->lv[l + 1].diag.p != nullptr;
+}
+// up: last post-smoothing sweep of level l+1 + prolongation into level l
+bool fuses_jacobi_prolong(const amg_hip_solver* s, int l) {
+  if (l + 2 >= (int)s->lv.size()) return false;  // the coarsest level is solved, not smoothed
+  const Level& L = s->lv[l];
+  const DevMat& AC = s->lv[l + 1].A_cols();
+  return jacobi_fuses_zero(s) && !jacobi_fuses_prolong(s, l) && L.linear &&
+         s->opt.stencil_transfers && AC.dict && AC.dict_shift == 0;
+}
+
+// phase 3: the first sweep was already done by the fused kernel of the finer level
+// (result in tmp).  prolong_into >= 0: the last sweep also adds P u_l to that level's u.
+amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolong_into = -1) {
   Level& L = s->lv[l];
   hipStream_t st = s->stream;
   const int iters = s->opt.smoother_iters;
@@ -405,7 +425,10 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0) {
       double* a = L.u.as<double>();
       double* b = L.tmp.as<double>();
       int it = 0;
-      if (phase == 1 && jacobi_fuses_zero(s)) {
+      if (phase == 3) {
+        std::swap(a, b);
+        it = 1;
+      } else if (phase == 1 && jacobi_fuses_zero(s)) {
         HIP_TRY(launch_jacobi_from_zero(L.n, L.diag.as<double>(), L.f.as<double>(), b,
                                         s->opt.omega, st));
         std::swap(a, b);
@@ -420,7 +443,16 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0) {
         it = 1;
       }
       for (; it < iters; ++it) {
-        HIP_TRY(launch_mat(CSR_JACOBI, A, a, L.f.as<double>(), b, s->opt.omega, st));
+        if (prolong_into >= 0 && it == iters - 1) {
+          Level& F = s->lv[prolong_into];
+          HIP_TRY(launch_dict_jacobi_prolong(A.n_rows, A.dict_words, A.dict_wmax, A.dict_nt,
+                                             A.dcodes.as<uint64_t>(), A.doff.as<int32_t>(),
+                                             A.dval.as<double>(), A.dict_ntab, a,
+                                             L.f.as<double>(), b, s->opt.omega, F.n,
+                                             F.u.as<double>(), st));
+        } else {
+          HIP_TRY(launch_mat(CSR_JACOBI, A, a, L.f.as<double>(), b, s->opt.omega, st));
+        }
         std::swap(a, b);
       }
       if (iters & 1)  // result sits in tmp: bring it home (keeps the graph static)
@@ -464,9 +496,25 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
   const int nl = (int)s->lv.size();
   hipStream_t st = s->stream;
   const bool zero_known = jacobi_fuses_zero(s);  // coarse pre-smoothing starts from u == 0
+  bool first_sweep_done = false;  // by the fused residual+restrict kernel of level l-1
   for (int l = 0; l < nl; ++l) {
-    amg_hip_status r = enqueue_smooth(s, l, (l >= 1 && zero_known) ? 1 : 0);  // :268
+    amg_hip_status r =
+        enqueue_smooth(s, l, first_sweep_done ? 3 : (l >= 1 && zero_known) ? 1 : 0);  // :268
     if (r != AMG_HIP_OK) return r;
+    first_sweep_done = false;
+    if (fuses_resid_restrict(s, l)) {                              // :272-282 + :268 of l+1
+      Level& L = s->lv[l];
+      Level& C = s->lv[l + 1];
+      const DevMat& A = L.A_rows;
+      HIP_TRY(launch_dict_resid_restrict(A.n_rows, A.dict_words, A.dict_wmax, A.dict_nt,
+                                         A.dcodes.as<uint64_t>(), A.doff.as<int32_t>(),
+                                         A.dval.as<double>(), A.dict_ntab, L.u.as<double>(),
+                                         L.f.as<double>(), L.r.as<double>(), C.n,
+                                         C.f.as<double>(), C.diag.as<double>(),
+                                         C.tmp.as<double>(), s->opt.omega, st));
+      first_sweep_done = true;
+      continue;
+    }
     if ((r = enqueue_residual(s, l)) != AMG_HIP_OK) return r;      // :272-274
     if (l + 1 != nl) {
       Level& L = s->lv[l];
@@ -501,12 +549,16 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
   for (int l = nl - 2; l >= 0; --l) {                              // :291
     Level& L = s->lv[l];
     Level& C = s->lv[l + 1];
+    // the last sweep of this level also prolongs into level l-1 when that fuses
+    const int into = (l >= 1 && fuses_jacobi_prolong(s, l - 1)) ? l - 1 : -1;
     if (jacobi_fuses_prolong(s, l)) {                              // :294-296 inside :300
-      amg_hip_status r = enqueue_smooth(s, l, 2);
+      amg_hip_status r = enqueue_smooth(s, l, 2, into);
       if (r != AMG_HIP_OK) return r;
       continue;
     }
-    if (L.linear && s->opt.stencil_transfers) {                    // :294-296
+    if (fuses_jacobi_prolong(s, l)) {
+      // :294-296 was done by the last sweep of level l+1
+    } else if (L.linear && s->opt.stencil_transfers) {             // :294-296
       HIP_TRY(launch_linear_prolong_add(L.n, C.n, C.u.as<double>(), L.u.as<double>(), st));
     } else {
       const DevCsr& P = L.P_rows;
@@ -515,7 +567,7 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
                          L.tmp.as<double>(), 1.0, 0, st));
       HIP_TRY(launch_add_inplace(L.n, L.tmp.as<double>(), L.u.as<double>(), st));
     }
-    amg_hip_status r = enqueue_smooth(s, l);                       // :300
+    amg_hip_status r = enqueue_smooth(s, l, 0, into);              // :300
     if (r != AMG_HIP_OK) return r;
   }
   return AMG_HIP_OK;
@@ -789,7 +841,6 @@ void amg_hip_set_index16(int32_t on) { g_index16 = on ? 1 : 0; }
 void amg_hip_set_nontemporal(int32_t on) { g_nontemporal = on ? 1 : 0; }
 void amg_hip_set_xcd_mapping(int32_t on) { set_xcd_mapping(on); }
 void amg_hip_set_dict_rows(int32_t rows_per_lane) { set_dict_rows_per_lane(rows_per_lane); }
-void amg_hip_set_dict_persistent(int32_t blocks_per_cu) { set_dict_persistent(blocks_per_cu); }
 
 void amg_hip_set_default_layout(int32_t layout) {
   if (layout >= AMG_HIP_LAYOUT_AUTO && layout <= AMG_HIP_LAYOUT_DICT) g_default_layout = layout;

@@ -73,7 +73,6 @@ def run_single(args):
         amg.lib().amg_hip_set_nontemporal(0)
     amg.set_dict_rows(args.dict_rows)
     amg.set_xcd_mapping(not args.no_xcd_map)
-    amg.set_dict_persistent(args.dict_persistent)
     amg.set_default_layout({"auto": amg.LAYOUT_AUTO, "csr": amg.LAYOUT_CSR, "sell": amg.LAYOUT_SELL,
                             "dict": amg.LAYOUT_DICT}[args.layout])
     t0 = time.time()
@@ -196,8 +195,6 @@ def main():
     ap.add_argument("--no-nt", action="store_true", help="disable the non-temporal matrix stream")
     ap.add_argument("--no-xcd-map", action="store_true", help="K-Dict: plain blockIdx -> tile mapping")
     ap.add_argument("--dict-rows", type=int, default=2, choices=[1, 2], help="K-Dict rows per lane")
-    ap.add_argument("--dict-persistent", type=int, default=0,
-                    help="K-Dict persistent workgroups per CU on large levels (0 = one tile per workgroup)")
     ap.add_argument("--fast-coarse", action="store_true",
                     help="partitioned (parallel) coarse solve; then fewer levels pay off (--levels 13)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

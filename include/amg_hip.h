@@ -127,11 +127,6 @@ void amg_hip_set_xcd_mapping(int32_t on);
 /* K-Dict rows per lane: 2 (default; 16-byte lane accesses) or 1.  Process-wide;
  * bit-identical results, a tuning / test switch.                                */
 void amg_hip_set_dict_rows(int32_t rows_per_lane);
-/* K-Dict on large levels: k > 0 persistent workgroups per CU that prefetch their
- * next tile (at most k, never more than fit at once); 0 = one tile per workgroup
- * (default: measured as fast); k < 0 = always persistent with |k| workgroups in total (test
- * hook: small matrices then walk many tiles per workgroup).                      */
-void amg_hip_set_dict_persistent(int32_t blocks_per_cu);
 
 /* Number of usable HIP devices (0 when none; never fails). */
 int amg_hip_device_count(void);

@@ -3,6 +3,15 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm and libamg_hip.so both depend on a libamdhip64.so.7 (torch bundles its
+# own); the first one loaded serves the whole process, and torch cannot initialise on
+# the system copy.  Tests that hand torch tensors to the C ABI need torch's copy, so it
+# is loaded before the library, whatever the test order.
+try:
+    import torch  # noqa: F401
+except ImportError:  # the C-ABI tests do not need it
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
