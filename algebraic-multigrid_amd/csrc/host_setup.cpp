@@ -212,6 +212,11 @@ bool to_dict(const Sparse& M, int64_t diag_shift, DictMat* D) {
   int32_t mw = 0;
   for (int64_t r = 0; r < n; ++r) mw = std::max(mw, M.ptr[r + 1] - M.ptr[r]);
   if (mw > 16) return false;
+  // byte offsets are 32-bit, and the gather of a "no entry" slot reads the row's
+  // diagonal column, which therefore has to exist
+  if (n >= ((int64_t)1 << 28) || M.n_inner >= ((int64_t)1 << 28) || diag_shift < 0 ||
+      n + diag_shift > M.n_inner)
+    return false;
   D->n = n;
   D->max_width = mw;
   D->words = mw > 8 ? 2 : 1;

@@ -457,47 +457,86 @@ __device__ __forceinline__ void dict_fetch(DictStream<WORDS, R>& s, int row0, in
     if (MODE == CSR_JACOBI) s.xi[0] = x[row0 + dshift];
   }
 }
-// decode + gather + row arithmetic of the R rows of one lane
+// One 32-byte LDS entry per code.  Entry 255 (= no entry) is all zero: its gather reads
+// the row's diagonal column (always a valid address).
+// Jacobi sweeps stage  a = value of an OFF-diagonal pair (else +0.0),
+//                      d = value of a diagonal pair (else +0.0);
+// the other modes      a = value.
+struct DictEntry {
+  double a;
+  double d;
+  int32_t off8;  // BYTE offset of the column from the row's diagonal column
+  int32_t pad[3];
+};
+template <int MODE>
+__device__ __forceinline__ void dict_stage_table(DictEntry* tab, const int32_t* __restrict__ doff,
+                                                 const double* __restrict__ dval, int ntab) {
+  const int t = threadIdx.x;  // 256 threads, 256 entries
+  const double v = t < ntab ? dval[t] : 0.0;
+  const int32_t o = t < ntab ? doff[t] : 0;
+  DictEntry e;
+  e.a = (MODE == CSR_JACOBI && o == 0) ? 0.0 : v;
+  e.d = (MODE == CSR_JACOBI && o == 0 && t < ntab) ? v : 0.0;
+  e.off8 = o * 8;
+  e.pad[0] = e.pad[1] = e.pad[2] = 0;
+  tab[t] = e;
+}
+// decode + gather + row arithmetic of the R rows of one lane.  The kernels are issue
+// bound as much as bandwidth bound (a wave64 VALU instruction occupies its SIMD for 4
+// cycles), so the row walk is branch-free and short: per entry one byte extract, one
+// 16-byte + one 4-byte LDS read, one 32-bit add for the byte offset (the gather uses
+// the scalar-base + 32-bit-offset addressing mode), mul, add.
+//
+// Skipped terms and bit-identity.  A Jacobi sweep adds (+0.0) * x for "no entry" slots
+// and for the diagonal pair, i.e. +-0.0 for finite x: acc + (+-0.0) == acc because a sum
+// that starts at +0.0 is never -0.0, and diag + (+0.0) == diag, so for finite vectors
+// the result has the same bits as skipping those terms (the x read there is the row's
+// own u_i, which enters the result anyway).  The other modes skip "no entry" slots
+// with a select: acc - (+0.0) == acc holds for every acc.
 template <int MODE, int WORDS, int UN, int R>
 __device__ __forceinline__ void dict_rows(const DictStream<WORDS, R>& s, int row0,
-                                          const double* s_val, const int32_t* s_off,
-                                          const double* x, double omega, int dshift,
-                                          double (&res)[R]) {
-  int c[R][UN];
-  double v[R][UN], xx[R][UN];
+                                          const DictEntry* tab, const double* x, double omega,
+                                          int dshift, double (&res)[R]) {
+  uint32_t c8[R][UN];
+  double v[R][UN], vd[R][UN], xx[R][UN];
   bool ok[R][UN];
+  const char* xb = reinterpret_cast<const char*>(x);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int drow = s.live[r] ? row0 + r + dshift : 0;
+    const uint32_t drow8 = s.live[r] ? (uint32_t)(row0 + r + dshift) * 8u : 0u;
+    const uint32_t w32[4] = {(uint32_t)s.cw[r][0], (uint32_t)(s.cw[r][0] >> 32),
+                             (uint32_t)s.cw[r][1], (uint32_t)(s.cw[r][1] >> 32)};
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int code = (int)((s.cw[r][u >> 3] >> (8 * (u & 7))) & 0xFF);
-      ok[r][u] = code != 0xFF;
-      const int cc = ok[r][u] ? code : 0;
-      c[r][u] = ok[r][u] ? drow + s_off[cc] : 0;  // x[0] is always valid
-      v[r][u] = s_val[cc];
+      const uint32_t code = (w32[u >> 2] >> (8 * (u & 3))) & 0xFFu;
+      ok[r][u] = code != 0xFFu;
+      c8[r][u] = drow8 + (uint32_t)tab[code].off8;
+      v[r][u] = tab[code].a;
+      vd[r][u] = (MODE == CSR_JACOBI) ? tab[code].d : 0.0;
     }
   }
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int u = 0; u < UN; ++u) xx[r][u] = x[c[r][u]];
+    for (int u = 0; u < UN; ++u)
+      xx[r][u] = *reinterpret_cast<const double*>(xb + c8[r][u]);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int drow = s.live[r] ? row0 + r + dshift : 0;
     double acc = (MODE == CSR_RESID) ? s.fi[r] : 0.0;
     double diag = 0.0;
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      if (ok[r][u]) {
-        if (MODE == CSR_RESID) {
-          acc -= v[r][u] * xx[r][u];
-        } else if (MODE == CSR_JACOBI) {
-          if (c[r][u] == drow) diag = v[r][u];
-          else acc += v[r][u] * xx[r][u];
-        } else {
-          acc += v[r][u] * xx[r][u];
-        }
+      double t = v[r][u] * xx[r][u];
+      if (MODE == CSR_JACOBI) {
+        acc += t;
+        diag += vd[r][u];
+      } else {
+        // the empty asm keeps the product unconditional, so that clang does not turn
+        // the select into an exec-masked branch with the gather (and its wait) inside
+        asm volatile("" : "+v"(t));
+        t = ok[r][u] ? t : 0.0;
+        if (MODE == CSR_RESID) acc -= t;
+        else acc += t;
       }
     }
     if (MODE == CSR_RESID || MODE == CSR_SPMV) {
@@ -540,18 +579,14 @@ __global__ __launch_bounds__(256) void dict_kernel(
     int n, const uint64_t* __restrict__ codes, const int32_t* __restrict__ doff,
     const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
     double* out, double omega, int dshift, int xcd_map) {
-  __shared__ double s_val[256];
-  __shared__ int32_t s_off[256];
+  __shared__ DictEntry tab[256];
   const int row0 = (xcd_tile(blockIdx.x, gridDim.x, xcd_map) * 256 + (int)threadIdx.x) * R;
   DictStream<WORDS, R> s;
   dict_fetch<MODE, WORDS, NT, R>(s, row0, n, codes, f, x, dshift);  // in flight while the table is staged
-  if ((int)threadIdx.x < ntab) {
-    s_val[threadIdx.x] = dval[threadIdx.x];
-    s_off[threadIdx.x] = doff[threadIdx.x];
-  }
+  dict_stage_table<MODE>(tab, doff, dval, ntab);
   __syncthreads();
   double res[R];
-  dict_rows<MODE, WORDS, UN, R>(s, row0, s_val, s_off, x, omega, dshift, res);
+  dict_rows<MODE, WORDS, UN, R>(s, row0, tab, x, omega, dshift, res);
   dict_store<WORDS, NT, R>(s, row0, res, out);
 }
 
@@ -572,20 +607,16 @@ __global__ __launch_bounds__(256) void dict_resid_restrict_kernel(
     const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
     double* r_out, int nH, double* __restrict__ fH, const double* __restrict__ diagH,
     double* __restrict__ uH1, double omega, int xcd_map) {
-  __shared__ double s_val[256];
-  __shared__ int32_t s_off[256];
+  __shared__ DictEntry tab[256];
   __shared__ double rs[256 * R];
   const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
   const int row0 = tile * (256 * R - 2) + (int)threadIdx.x * R;
   DictStream<WORDS, R> s;
   dict_fetch<CSR_RESID, WORDS, NT, R>(s, row0, n, codes, f, x, 0);
-  if ((int)threadIdx.x < ntab) {
-    s_val[threadIdx.x] = dval[threadIdx.x];
-    s_off[threadIdx.x] = doff[threadIdx.x];
-  }
+  dict_stage_table<CSR_RESID>(tab, doff, dval, ntab);
   __syncthreads();
   double res[R];
-  dict_rows<CSR_RESID, WORDS, UN, R>(s, row0, s_val, s_off, x, omega, 0, res);
+  dict_rows<CSR_RESID, WORDS, UN, R>(s, row0, tab, x, omega, 0, res);
   dict_store<WORDS, NT, R>(s, row0, res, r_out);
 #pragma unroll
   for (int r = 0; r < R; ++r) rs[threadIdx.x * R + r] = s.live[r] ? res[r] : 0.0;
@@ -613,21 +644,17 @@ __global__ __launch_bounds__(256) void dict_jacobi_prolong_kernel(
     const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
     double* out, double omega, int n_h, double* uh, int xcd_map) {
   typedef double f64x2 __attribute__((ext_vector_type(2)));
-  __shared__ double s_val[256];
-  __shared__ int32_t s_off[256];
+  __shared__ DictEntry tab[256];
   __shared__ double rs[256 * R];
   const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
   const int stride = 256 * R - 2;
   const int row0 = tile * stride + (int)threadIdx.x * R;
   DictStream<WORDS, R> s;
   dict_fetch<CSR_JACOBI, WORDS, NT, R>(s, row0, n, codes, f, x, 0);
-  if ((int)threadIdx.x < ntab) {
-    s_val[threadIdx.x] = dval[threadIdx.x];
-    s_off[threadIdx.x] = doff[threadIdx.x];
-  }
+  dict_stage_table<CSR_JACOBI>(tab, doff, dval, ntab);
   __syncthreads();
   double res[R];
-  dict_rows<CSR_JACOBI, WORDS, UN, R>(s, row0, s_val, s_off, x, omega, 0, res);
+  dict_rows<CSR_JACOBI, WORDS, UN, R>(s, row0, tab, x, omega, 0, res);
   dict_store<WORDS, NT, R>(s, row0, res, out);
 #pragma unroll
   for (int r = 0; r < R; ++r) rs[threadIdx.x * R + r] = s.live[r] ? res[r] : 0.0;
