@@ -478,6 +478,36 @@ def test_jacobi_fusions_and_zero_pruning_are_bit_neutral(amg, oracle):
     mg.close()
 
 
+def test_fused_level_kernels_at_tile_boundaries(amg, oracle):
+    """The fused residual+restriction+first-coarse-sweep and sweep+prolongation kernels
+    work on overlapping tiles of 256 or 512 rows (stride 254 / 510, one or two rows per
+    lane from 4096 rows on): sizes around every boundary, odd and even, against the
+    oracle bit for bit on every level vector (u, f, r)."""
+    for n in (253, 254, 255, 256, 257, 509, 510, 511, 512, 513, 765, 1019, 1020, 1021, 1022,
+              4095, 4096, 4097, 4605, 4606, 4607, 5117, 8191):
+        cp = np.zeros(n + 1, dtype=np.int32)
+        ri, va = [], []
+        for j in range(n):        # tridiagonal, diagonally dominant, row-dependent values
+            for i in (j - 1, j, j + 1):
+                if 0 <= i < n:
+                    ri.append(i)
+                    va.append(2.5 + 0.25 * ((j * 7) % 5) if i == j else -1.0 - 0.125 * ((i + j) % 3))
+            cp[j + 1] = len(ri)
+        A = oracle.CSC(n, n, cp, np.array(ri, dtype=np.int32), np.array(va))
+        b = np.cos(0.37 * np.arange(n)) + 1.5
+        L = 3
+        ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
+        mg = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
+        for c in range(2):
+            ref.vcycle()
+            mg.vcycle()
+            for l in range(L):
+                assert np.array_equal(mg.get_soln(l), ref.get_vec(l, "u")), (n, c, l)
+                assert np.array_equal(mg.get_rhs(l), ref.get_vec(l, "f")), (n, c, l)
+                assert np.array_equal(mg.get_residual(l), ref.get_vec(l, "r")), (n, c, l)
+        mg.close()
+
+
 def test_partitioned_coarse_solve(amg, oracle, mats):
     """opt.fast_coarse_solve: the banded LDL^T solve cut into partitions that are solved
     in parallel and coupled by a short boundary recurrence.  Same direct solve as the
