@@ -207,7 +207,7 @@ void to_sell64(const Sparse& M, Sell64* S) {
   }
 }
 
-bool to_dict(const Sparse& M, int64_t diag_shift, DictMat* D) {
+bool to_dict(const Sparse& M, int64_t diag_shift, DictMat* D, const int32_t* rowid) {
   const int64_t n = M.n_outer;
   int32_t mw = 0;
   for (int64_t r = 0; r < n; ++r) mw = std::max(mw, M.ptr[r + 1] - M.ptr[r]);
@@ -215,7 +215,7 @@ bool to_dict(const Sparse& M, int64_t diag_shift, DictMat* D) {
   // byte offsets are 32-bit, and the gather of a "no entry" slot reads the row's
   // diagonal column, which therefore has to exist
   if (n >= ((int64_t)1 << 28) || M.n_inner >= ((int64_t)1 << 28) || diag_shift < 0 ||
-      n + diag_shift > M.n_inner)
+      (!rowid && n + diag_shift > M.n_inner))
     return false;
   D->n = n;
   D->max_width = mw;
@@ -230,7 +230,7 @@ bool to_dict(const Sparse& M, int64_t diag_shift, DictMat* D) {
     uint64_t w[2] = {~(uint64_t)0, ~(uint64_t)0};
     int j = 0;
     for (int32_t q = M.ptr[r]; q < M.ptr[r + 1]; ++q, ++j) {
-      const int64_t d = (int64_t)M.idx[q] - (r + diag_shift);
+      const int64_t d = (int64_t)M.idx[q] - (rowid ? (int64_t)rowid[r] : r + diag_shift);
       if (d < INT32_MIN / 2 || d > INT32_MAX / 2) return false;
       uint64_t bits;
       std::memcpy(&bits, &M.val[q], 8);

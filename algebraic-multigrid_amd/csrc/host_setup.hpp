@@ -76,8 +76,11 @@ struct DictMat {
   std::vector<int32_t> doff;    // table: column offset from the row's diagonal column
   std::vector<double> dval;     // table: value
 };
-// false when the matrix does not qualify (more than 255 pairs or a row > 16 entries)
-bool to_dict(const Sparse& rows_as, int64_t diag_shift, DictMat* out);
+// false when the matrix does not qualify (more than 255 pairs or a row > 16 entries).
+// rowid (optional): dof of every storage row (colour-permuted copies; -1 = empty padding
+// row); offsets are then taken from column rowid[r] instead of r + diag_shift.
+bool to_dict(const Sparse& rows_as, int64_t diag_shift, DictMat* out,
+             const int32_t* rowid = nullptr);
 
 // ---- coarsest level: banded LDL^T (replaces Eigen::SimplicialLDLT) ---------
 struct BandFactor {

@@ -475,8 +475,9 @@ __device__ __forceinline__ void dict_stage_table(DictEntry* tab, const int32_t* 
   const double v = t < ntab ? dval[t] : 0.0;
   const int32_t o = t < ntab ? doff[t] : 0;
   DictEntry e;
-  e.a = (MODE == CSR_JACOBI && o == 0) ? 0.0 : v;
-  e.d = (MODE == CSR_JACOBI && o == 0 && t < ntab) ? v : 0.0;
+  constexpr bool split = MODE == CSR_JACOBI || MODE == CSR_GS;
+  e.a = (split && o == 0) ? 0.0 : v;
+  e.d = (split && o == 0 && t < ntab) ? v : 0.0;
   e.off8 = o * 8;
   e.pad[0] = e.pad[1] = e.pad[2] = 0;
   tab[t] = e;
@@ -512,7 +513,7 @@ __device__ __forceinline__ void dict_rows(const DictStream<WORDS, R>& s, int row
       ok[r][u] = code != 0xFFu;
       c8[r][u] = drow8 + (uint32_t)tab[code].off8;
       v[r][u] = tab[code].a;
-      vd[r][u] = (MODE == CSR_JACOBI) ? tab[code].d : 0.0;
+      vd[r][u] = (MODE == CSR_JACOBI || MODE == CSR_GS) ? tab[code].d : 0.0;
     }
   }
 #pragma unroll
@@ -527,7 +528,7 @@ __device__ __forceinline__ void dict_rows(const DictStream<WORDS, R>& s, int row
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       double t = v[r][u] * xx[r][u];
-      if (MODE == CSR_JACOBI) {
+      if (MODE == CSR_JACOBI || MODE == CSR_GS) {
         acc += t;
         diag += vd[r][u];
       } else {
@@ -543,6 +544,8 @@ __device__ __forceinline__ void dict_rows(const DictStream<WORDS, R>& s, int row
       res[r] = acc;
     } else if (MODE == CSR_JACOBI) {
       res[r] = (diag == 0.0) ? s.xi[r] : s.xi[r] + omega * ((s.fi[r] - acc) / diag - s.xi[r]);
+    } else if (MODE == CSR_GS) {
+      res[r] = (diag == 0.0) ? s.xi[r] : (s.fi[r] - acc) / diag;  // smoother.hpp:136
     } else {
       const double d = s.fi[r] - acc;
       res[r] = d * d;
@@ -601,12 +604,13 @@ __global__ __launch_bounds__(256) void dict_kernel(
 // (1) residual + restriction + first coarse Jacobi sweep (multigrid.hpp:272-282, then
 // :268 on level l+1 whose u is zero): r = f - A u is written, f_H = R r is written, and
 // the from-zero sweep of the coarse level (jacobi_from_zero_kernel) is written to uH1.
+// Other smoothers (uH1 == nullptr): the coarse u is zero-filled instead (uH0, :278).
 template <int WORDS, int UN, bool NT, int R>
 __global__ __launch_bounds__(256) void dict_resid_restrict_kernel(
     int n, const uint64_t* __restrict__ codes, const int32_t* __restrict__ doff,
     const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
     double* r_out, int nH, double* __restrict__ fH, const double* __restrict__ diagH,
-    double* __restrict__ uH1, double omega, int xcd_map) {
+    double* __restrict__ uH1, double* __restrict__ uH0, double omega, int xcd_map) {
   __shared__ DictEntry tab[256];
   __shared__ double rs[256 * R];
   const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
@@ -630,9 +634,13 @@ __global__ __launch_bounds__(256) void dict_resid_restrict_kernel(
     if (i + 1 < n) sum += 1.0 * rs[2 * q + 1];
     if (i + 2 < n) sum += 0.5 * rs[2 * q + 2];
     fH[j] = sum;
-    const double xi = 0.0, acc = 0.0;  // jacobi_from_zero_kernel
-    const double d = diagH[j];
-    uH1[j] = (d == 0.0) ? xi : xi + omega * ((sum - acc) / d - xi);
+    if (uH1) {
+      const double xi = 0.0, acc = 0.0;  // jacobi_from_zero_kernel
+      const double d = diagH[j];
+      uH1[j] = (d == 0.0) ? xi : xi + omega * ((sum - acc) / d - xi);
+    } else {
+      uH0[j] = 0.0;  // multigrid.hpp:278
+    }
   }
 }
 // (2) Jacobi sweep on level H + prolongation of its result into the finer level
@@ -725,6 +733,68 @@ static hipError_t launch_dict_mode(int64_t n, int words, int wmax, bool nt, cons
   AMG_DICT(2, 16);
 #undef AMG_DICT
 }
+// ---- one colour of the multicolour Gauss-Seidel sweep, dictionary-coded -----------------
+// Storage rows [p0, p0 + count) are the rows of one colour (host_setup.hpp: ColorPerm),
+// rowid[p] the dof each one updates (-1 = padding); codes are indexed by storage row,
+// offsets are relative to the dof.  u is updated in place: rows of one colour do not
+// reference each other.  Same arithmetic as K-SELL's CSR_GS mode.
+template <int WORDS, int UN>
+__global__ __launch_bounds__(256) void dict_gs_color_kernel(
+    int p0, int count, const uint64_t* __restrict__ codes, const int32_t* __restrict__ rowid,
+    const int32_t* __restrict__ doff, const double* __restrict__ dval, int ntab,
+    const double* __restrict__ f, double* u, int xcd_map) {
+  typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+  __shared__ DictEntry tab[256];
+  const int k = xcd_tile(blockIdx.x, gridDim.x, xcd_map) * 256 + (int)threadIdx.x;
+  const int p = p0 + k;
+  const int row = k < count ? rowid[p] : -1;
+  DictStream<WORDS, 1> s;
+  s.live[0] = row >= 0;
+  s.cw[0][0] = s.cw[0][1] = ~(uint64_t)0;
+  s.fi[0] = s.xi[0] = 0.0;
+  if (s.live[0]) {
+    const uint64_t* cp = codes + (int64_t)p * WORDS;
+    if (WORDS == 2) {
+      const u64x2 t = *reinterpret_cast<const u64x2*>(cp);
+      s.cw[0][0] = t.x; s.cw[0][1] = t.y;
+    } else {
+      s.cw[0][0] = cp[0];
+    }
+    s.fi[0] = f[row];
+    s.xi[0] = u[row];
+  }
+  dict_stage_table<CSR_GS>(tab, doff, dval, ntab);
+  __syncthreads();
+  double res[1];
+  dict_rows<CSR_GS, WORDS, UN, 1>(s, s.live[0] ? row : 0, tab, u, 1.0, 0, res);
+  if (s.live[0]) u[row] = res[0];
+}
+hipError_t launch_dict_gs_color(int64_t p0, int64_t count, int words, int wmax,
+                                const uint64_t* codes, const int32_t* rowid, const int32_t* doff,
+                                const double* dval, int ntab, const double* f, double* u,
+                                hipStream_t st) {
+  if (count <= 0) return hipSuccess;
+  if (p0 + count >= ((int64_t)1 << 31) - 512 || ntab > 255 || (words != 1 && words != 2) ||
+      wmax > 8 * words)
+    return hipErrorInvalidValue;
+  const unsigned grid = (unsigned)((count + 255) / 256);
+#define AMG_DICT_GS(W, U)                                                                       \
+  hipLaunchKernelGGL((dict_gs_color_kernel<W, U>), dim3(grid), dim3(256), 0, st, (int)p0,        \
+                     (int)count, codes, rowid, doff, dval, ntab, f, u, g_xcd_map)
+  if (words == 1) {
+    if (wmax <= 3) AMG_DICT_GS(1, 3);
+    else if (wmax <= 5) AMG_DICT_GS(1, 5);
+    else if (wmax <= 7) AMG_DICT_GS(1, 7);
+    else AMG_DICT_GS(1, 8);
+  } else {
+    if (wmax <= 9) AMG_DICT_GS(2, 9);
+    else if (wmax <= 12) AMG_DICT_GS(2, 12);
+    else AMG_DICT_GS(2, 16);
+  }
+#undef AMG_DICT_GS
+  return hipGetLastError();
+}
+
 // (W, U) dispatch shared by the fused launchers: F is a generic lambda taking
 // std::integral_constant<int, W>, <int, U>, <bool, NT>, <int, R>
 template <class F>
@@ -762,10 +832,10 @@ hipError_t launch_dict_resid_restrict(int64_t n, int words, int wmax, int nt,
                                       const uint64_t* codes, const int32_t* doff,
                                       const double* dval, int ntab, const double* x,
                                       const double* f, double* r_out, int64_t nH, double* fH,
-                                      const double* diagH, double* uH1, double omega,
-                                      hipStream_t st) {
+                                      const double* diagH, double* uH1, double* uH0,
+                                      double omega, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  if (!dict_args_ok(n, words, wmax, ntab) || nH > n || !fH || !diagH || !uH1)
+  if (!dict_args_ok(n, words, wmax, ntab) || nH > n || !fH || (uH1 ? !diagH : !uH0))
     return hipErrorInvalidValue;
   const bool two = g_dict_rows_per_lane == 2 && n >= 4096 && aligned16(f, r_out, codes);
   const int64_t stride = 256 * (two ? 2 : 1) - 2;
@@ -774,7 +844,7 @@ hipError_t launch_dict_resid_restrict(int64_t n, int words, int wmax, int nt,
     hipLaunchKernelGGL((dict_resid_restrict_kernel<decltype(W)::value, decltype(U)::value,
                                                    decltype(NTF)::value, decltype(RR)::value>),
                        dim3(tiles), dim3(256), 0, st, (int)n, codes, doff, dval, ntab, x, f, r_out,
-                       (int)nH, fH, diagH, uH1, omega, g_xcd_map);
+                       (int)nH, fH, diagH, uH1, uH0, omega, g_xcd_map);
   });
 }
 hipError_t launch_dict_jacobi_prolong(int64_t n, int words, int wmax, int nt,

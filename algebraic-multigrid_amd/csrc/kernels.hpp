@@ -10,7 +10,7 @@ enum CsrMode {
   CSR_JACOBI = 1,  // out = x_i + omega*((f_i - sum_{j!=i} a_ij x_j)/a_ii - x_i)
   CSR_SPMV = 2,    // out = A x
   CSR_RSSQ = 3,    // out_i = (f_i - (A x)_i)^2
-  CSR_GS = 4,      // in-place Gauss-Seidel update of one colour (K-SELL only)
+  CSR_GS = 4,      // in-place Gauss-Seidel update of one colour
   CSR_JACOBI_P = 5 // Jacobi sweep whose input is x + P*uH (linear P), K-SELL only
 };
 
@@ -33,14 +33,20 @@ hipError_t launch_sell(int mode, int64_t n, int idx16, const int64_t* soff,
 // K-Dict: dictionary-coded rows (host_setup.hpp: DictMat); modes as launch_sell.
 void set_xcd_mapping(int on);  // contiguous run of tiles per XCD (default on)
 void set_dict_rows_per_lane(int r);  // 1 or 2 (default), tuning / test switch
+// one colour of the multicolour GS sweep on a dictionary-coded colour-permuted copy
+hipError_t launch_dict_gs_color(int64_t p0, int64_t count, int words, int wmax,
+                                const uint64_t* codes, const int32_t* rowid, const int32_t* doff,
+                                const double* dval, int ntab, const double* f, double* u,
+                                hipStream_t st);
 // fused forms for the true-Jacobi V-cycle on linear-interpolation levels (kernels.hip):
-// r = f - A x (written), f_H = R r, uH1 = first Jacobi sweep of the coarse level from zero
+// r = f - A x (written), f_H = R r, and either uH1 = first Jacobi sweep of the coarse level
+// from zero (needs diagH) or, with uH1 == nullptr, uH0 = 0
 hipError_t launch_dict_resid_restrict(int64_t n, int words, int wmax, int nt,
                                       const uint64_t* codes, const int32_t* doff,
                                       const double* dval, int ntab, const double* x,
                                       const double* f, double* r_out, int64_t nH, double* fH,
-                                      const double* diagH, double* uH1, double omega,
-                                      hipStream_t st);
+                                      const double* diagH, double* uH1, double* uH0,
+                                      double omega, hipStream_t st);
 // out = Jacobi sweep of x on this (coarse) level, then uh += P out on the finer level
 hipError_t launch_dict_jacobi_prolong(int64_t n, int words, int wmax, int nt,
                                       const uint64_t* codes, const int32_t* doff,

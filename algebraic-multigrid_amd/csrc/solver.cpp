@@ -332,6 +332,9 @@ struct Level {
   DevMat mc_mat;
   DevMem mc_rowid;
   std::vector<int64_t> mc_start;
+  bool mc_dict = false;    // ... dictionary-coded instead (K-Dict colour kernel)
+  int mc_words = 0, mc_wmax = 0, mc_ntab = 0;
+  DevMem mc_codes, mc_doff, mc_dval;
 };
 
 }  // namespace
@@ -387,8 +390,11 @@ bool jacobi_fuses_prolong(const amg_hip_solver* s, int l) {
 bool fuses_resid_restrict(const amg_hip_solver* s, int l) {
   if (l + 1 >= (int)s->lv.size()) return false;
   const Level& L = s->lv[l];
-  return jacobi_fuses_zero(s) && L.linear && s->opt.stencil_transfers && L.A_rows.dict &&
-         L.A_rows.dict_shift == 0 && s->lv[l + 1].diag.p != nullptr;
+  if (s->opt.no_fusion || !L.linear || !s->opt.stencil_transfers || !L.A_rows.dict ||
+      L.A_rows.dict_shift != 0)
+    return false;
+  // true Jacobi: the kernel also does the first coarse sweep and needs the coarse diagonal
+  return !jacobi_fuses_zero(s) || s->lv[l + 1].diag.p != nullptr;
 }
 // up: last post-smoothing sweep of level l+1 + prolongation into level l
 bool fuses_jacobi_prolong(const amg_hip_solver* s, int l) {
@@ -474,6 +480,11 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
 amg_hip_status enqueue_multicolor(amg_hip_solver*, Level& L, hipStream_t st) {
   const DevMat& A = L.mc_mat;
   auto one = [&](int c) -> hipError_t {
+    if (L.mc_dict)
+      return launch_dict_gs_color(L.mc_start[c], L.mc_start[c + 1] - L.mc_start[c], L.mc_words,
+                                  L.mc_wmax, L.mc_codes.as<uint64_t>(), L.mc_rowid.as<int32_t>(),
+                                  L.mc_doff.as<int32_t>(), L.mc_dval.as<double>(), L.mc_ntab,
+                                  L.f.as<double>(), L.u.as<double>(), st);
     return launch_sell_gs_color(A.n_rows, A.max_width, A.soff.as<int64_t>(), A.scol.as<int32_t>(),
                                 A.sval.as<double>(), L.mc_rowid.as<int32_t>(), L.mc_start[c],
                                 L.mc_start[c + 1] - L.mc_start[c], L.f.as<double>(),
@@ -510,9 +521,11 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
                                          A.dcodes.as<uint64_t>(), A.doff.as<int32_t>(),
                                          A.dval.as<double>(), A.dict_ntab, L.u.as<double>(),
                                          L.f.as<double>(), L.r.as<double>(), C.n,
-                                         C.f.as<double>(), C.diag.as<double>(),
-                                         C.tmp.as<double>(), s->opt.omega, st));
-      first_sweep_done = true;
+                                         C.f.as<double>(),
+                                         zero_known ? C.diag.as<double>() : nullptr,
+                                         zero_known ? C.tmp.as<double>() : nullptr,
+                                         C.u.as<double>(), s->opt.omega, st));
+      first_sweep_done = zero_known;
       continue;
     }
     if ((r = enqueue_residual(s, l)) != AMG_HIP_OK) return r;      // :272-274
@@ -720,7 +733,19 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
       build_color_perm(L.A_csc, L.color, L.n_colors, &CP);  // column-as-row walk, like SpGS
       if (CP.rows.n_outer >= ((int64_t)1 << 31) - 512)
         return fail(AMG_HIP_EUNSUPPORTED, "multicolour smoother: level too large for int32 rows");
-      HIP_TRY(upload_mat(CP.rows, AMG_HIP_LAYOUT_SELL, &L.mc_mat, 0, false));
+      DictMat T;
+      L.mc_dict = (s->opt.layout == AMG_HIP_LAYOUT_AUTO || s->opt.layout == AMG_HIP_LAYOUT_DICT) &&
+                  to_dict(CP.rows, 0, &T, CP.rowid.data());
+      if (L.mc_dict) {
+        L.mc_words = T.words;
+        L.mc_wmax = T.max_width;
+        L.mc_ntab = (int)T.doff.size();
+        HIP_TRY(upload(L.mc_codes, T.codes.data(), T.codes.size()));
+        HIP_TRY(upload(L.mc_doff, T.doff.data(), T.doff.size()));
+        HIP_TRY(upload(L.mc_dval, T.dval.data(), T.dval.size()));
+      } else {
+        HIP_TRY(upload_mat(CP.rows, AMG_HIP_LAYOUT_SELL, &L.mc_mat, 0, false));
+      }
       HIP_TRY(upload(L.mc_rowid, CP.rowid.data(), CP.rowid.size()));
       L.mc_start = CP.start;
     }
