@@ -36,7 +36,8 @@ class Options(C.Structure):
                 ("stencil_transfers", C.c_int32), ("layout", C.c_int32),
                 ("host_only", C.c_int32), ("keep_structural_zeros", C.c_int32),
                 ("no_fusion", C.c_int32), ("fuse_prolong", C.c_int32),
-                ("fast_coarse_solve", C.c_int32), ("reserved", C.c_int32 * 2),
+                ("fast_coarse_solve", C.c_int32), ("host_galerkin", C.c_int32),
+                ("reserved", C.c_int32 * 1),
                 ("stream", C.c_void_p)]
 
 
@@ -246,7 +247,8 @@ class Multigrid:
                  smoother_iters=1, omega=1.0, tolerance=1e-9, compute_error_every_n_iters=10,
                  n_iters=100, device=-1, use_graph=True, stencil_transfers=True,
                  transfers=None, layout=None, host_only=False, keep_structural_zeros=False,
-                 no_fusion=False, fuse_prolong=False, stream=None, fast_coarse_solve=False):
+                 no_fusion=False, fuse_prolong=False, stream=None, fast_coarse_solve=False,
+                 host_galerkin=False):
         # multigrid.hpp:165-178 (same checks, same order)
         if compute_error_every_n_iters > n_iters:
             raise ValueError("`compute_error_every_n_iters` must be leq to `n_iters`, got "
@@ -270,6 +272,7 @@ class Multigrid:
         o.no_fusion = int(no_fusion)
         o.fuse_prolong = int(fuse_prolong)
         o.fast_coarse_solve = int(fast_coarse_solve)
+        o.host_galerkin = int(host_galerkin)
         if stream:
             o.stream = C.c_void_p(stream)
         h = C.c_void_p()

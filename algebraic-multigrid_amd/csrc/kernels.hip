@@ -1513,4 +1513,188 @@ hipError_t launch_band_solve(int64_t n, int m, const double* sched_f, const doub
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------ K-Galerkin -----
+// Setup on the device: A_H = R (A P) for the LinearInterpolator pair (P column j =
+// {0.5, 1, 0.5} on rows 2j..2j+2, R = P^T; multigrid.hpp:219-223), in Eigen's
+// conservative-product order: an output entry exists as soon as one product touches
+// it (exact zeros are kept), its first product is assigned and the others are added in
+// ascending inner index -- the same bits as host_setup.cpp: spgemm_csr.  Thread per
+// output row, two passes (count, fill) around an exclusive scan.
+//
+// Row i of A P.  Walking A's row in ascending k, the coarse columns that P's row k
+// holds (k odd: (k-1)/2; k even: k/2 - 1 and k/2) come out in non-decreasing order, so
+// one open accumulator is enough.
+template <bool FILL>
+__global__ __launch_bounds__(256) void galerkin_ap_kernel(
+    int64_t n_h, int64_t n_H, const int32_t* __restrict__ arp, const int32_t* __restrict__ acol,
+    const double* __restrict__ aval, int32_t* __restrict__ cnt, const int32_t* __restrict__ orp,
+    int32_t* __restrict__ ocol, double* __restrict__ oval) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_h) return;
+  int32_t n_out = 0;
+  int64_t cur = -1;
+  double acc = 0.0;
+  const int64_t base = FILL ? orp[i] : 0;
+  auto touch = [&](int64_t c, double t) {
+    if (c == cur) {
+      acc += t;
+    } else {
+      if (cur >= 0) {
+        if (FILL) { ocol[base + n_out] = (int32_t)cur; oval[base + n_out] = acc; }
+        ++n_out;
+      }
+      cur = c;
+      acc = t;  // first touch: assign
+    }
+  };
+  for (int32_t p = arp[i]; p < arp[i + 1]; ++p) {
+    const int64_t k = acol[p];
+    const double a = aval[p];
+    if (k & 1) {
+      const int64_t c = (k - 1) >> 1;
+      if (c < n_H) touch(c, a * 1.0);
+    } else {
+      const int64_t c = k >> 1;
+      if (c >= 1 && c - 1 < n_H) touch(c - 1, a * 0.5);  // P(2(c-1)+2, c-1)
+      if (c < n_H) touch(c, a * 0.5);                    // P(2c, c)
+    }
+  }
+  if (cur >= 0) {
+    if (FILL) { ocol[base + n_out] = (int32_t)cur; oval[base + n_out] = acc; }
+    ++n_out;
+  }
+  if (!FILL) cnt[i] = n_out;
+}
+// Row j of R (A P): three-way merge of rows 2j, 2j+1, 2j+2 of A P, products taken in
+// that order (R's row j in ascending column).
+template <bool FILL>
+__global__ __launch_bounds__(256) void galerkin_rap_kernel(
+    int64_t n_h, int64_t n_H, const int32_t* __restrict__ prp, const int32_t* __restrict__ pcol,
+    const double* __restrict__ pval, int32_t* __restrict__ cnt, const int32_t* __restrict__ orp,
+    int32_t* __restrict__ ocol, double* __restrict__ oval) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_H) return;
+  const double w[3] = {0.5, 1.0, 0.5};
+  int32_t q[3], e[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int64_t i = 2 * j + r;
+    q[r] = i < n_h ? prp[i] : 0;
+    e[r] = i < n_h ? prp[i + 1] : 0;
+  }
+  int32_t n_out = 0;
+  const int64_t base = FILL ? orp[j] : 0;
+  for (;;) {
+    int32_t c = INT32_MAX;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (q[r] < e[r]) { const int32_t cc = pcol[q[r]]; c = cc < c ? cc : c; }
+    if (c == INT32_MAX) break;
+    double v = 0.0;
+    bool started = false;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (q[r] < e[r] && pcol[q[r]] == c) {
+        const double t = w[r] * pval[q[r]];
+        v = started ? v + t : t;
+        started = true;
+        ++q[r];
+      }
+    if (FILL) { ocol[base + n_out] = c; oval[base + n_out] = v; }
+    ++n_out;
+  }
+  if (!FILL) cnt[j] = n_out;
+}
+// exclusive scan of n int32 counts into n + 1 offsets (three small kernels)
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(int64_t n, const int32_t* __restrict__ in,
+                                                              int64_t* __restrict__ bsum) {
+  __shared__ int64_t red[256];
+  const int64_t b0 = (int64_t)blockIdx.x * 1024;
+  int64_t sum = 0;
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = b0 + threadIdx.x * 4 + k;
+    if (i < n) sum += in[i];
+  }
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+}
+__global__ void scan_block_offsets_kernel(int64_t nb, int64_t* bsum, int64_t* total) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int64_t run = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t v = bsum[b];
+    bsum[b] = run;
+    run += v;
+  }
+  *total = run;
+}
+__global__ __launch_bounds__(256) void scan_finish_kernel(int64_t n, const int32_t* __restrict__ in,
+                                                          const int64_t* __restrict__ bsum,
+                                                          int32_t* __restrict__ out) {
+  __shared__ int64_t pre[256];
+  const int64_t b0 = (int64_t)blockIdx.x * 1024;
+  int32_t v[4];
+  int64_t sum = 0;
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = b0 + threadIdx.x * 4 + k;
+    v[k] = i < n ? in[i] : 0;
+    sum += v[k];
+  }
+  pre[threadIdx.x] = sum;
+  __syncthreads();
+  for (int st = 1; st < 256; st <<= 1) {  // inclusive scan of the per-thread sums
+    const int64_t add = (int)threadIdx.x >= st ? pre[threadIdx.x - st] : 0;
+    __syncthreads();
+    pre[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int64_t run = bsum[blockIdx.x] + pre[threadIdx.x] - sum;
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = b0 + threadIdx.x * 4 + k;
+    if (i < n) out[i] = (int32_t)run;
+    run += v[k];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = (int32_t)run;
+}
+// counts[0..n) -> offsets[0..n]; *total (device int64) = offsets[n]; bsum: ceil(n/1024) int64
+hipError_t launch_exclusive_scan(int64_t n, const int32_t* counts, int32_t* offsets, int64_t* bsum,
+                                 int64_t* total, hipStream_t st) {
+  if (n <= 0) return hipErrorInvalidValue;
+  const int64_t nb = (n + 1023) / 1024;
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, counts, bsum);
+  hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(1), 0, st, nb, bsum, total);
+  hipLaunchKernelGGL(scan_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, counts, bsum,
+                     offsets);
+  return hipGetLastError();
+}
+hipError_t launch_galerkin_ap(bool fill, int64_t n_h, int64_t n_H, const int32_t* arp,
+                              const int32_t* acol, const double* aval, int32_t* cnt,
+                              const int32_t* orp, int32_t* ocol, double* oval, hipStream_t st) {
+  const unsigned grid = (unsigned)((n_h + 255) / 256);
+  if (fill)
+    hipLaunchKernelGGL(galerkin_ap_kernel<true>, dim3(grid), dim3(256), 0, st, n_h, n_H, arp, acol,
+                       aval, cnt, orp, ocol, oval);
+  else
+    hipLaunchKernelGGL(galerkin_ap_kernel<false>, dim3(grid), dim3(256), 0, st, n_h, n_H, arp, acol,
+                       aval, cnt, orp, ocol, oval);
+  return hipGetLastError();
+}
+hipError_t launch_galerkin_rap(bool fill, int64_t n_h, int64_t n_H, const int32_t* prp,
+                               const int32_t* pcol, const double* pval, int32_t* cnt,
+                               const int32_t* orp, int32_t* ocol, double* oval, hipStream_t st) {
+  const unsigned grid = (unsigned)((n_H + 255) / 256);
+  if (fill)
+    hipLaunchKernelGGL(galerkin_rap_kernel<true>, dim3(grid), dim3(256), 0, st, n_h, n_H, prp, pcol,
+                       pval, cnt, orp, ocol, oval);
+  else
+    hipLaunchKernelGGL(galerkin_rap_kernel<false>, dim3(grid), dim3(256), 0, st, n_h, n_H, prp, pcol,
+                       pval, cnt, orp, ocol, oval);
+  return hipGetLastError();
+}
+
 }  // namespace amg_hip

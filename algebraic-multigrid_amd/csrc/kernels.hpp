@@ -142,4 +142,16 @@ struct SpikeArgs {
 };
 hipError_t launch_spike_solve(const SpikeArgs& a, hipStream_t st);
 
+// K-Galerkin (setup): A_H = R (A P) for the linear interpolation pair, on CSR arrays that
+// live on the device; count pass (fill = false: cnt[row]) / fill pass (orp = scanned
+// counts) around launch_exclusive_scan.  Same entry order and bits as spgemm_csr.
+hipError_t launch_exclusive_scan(int64_t n, const int32_t* counts, int32_t* offsets, int64_t* bsum,
+                                 int64_t* total, hipStream_t st);
+hipError_t launch_galerkin_ap(bool fill, int64_t n_h, int64_t n_H, const int32_t* arp,
+                              const int32_t* acol, const double* aval, int32_t* cnt,
+                              const int32_t* orp, int32_t* ocol, double* oval, hipStream_t st);
+hipError_t launch_galerkin_rap(bool fill, int64_t n_h, int64_t n_H, const int32_t* prp,
+                               const int32_t* pcol, const double* pval, int32_t* cnt,
+                               const int32_t* orp, int32_t* ocol, double* oval, hipStream_t st);
+
 }  // namespace amg_hip

@@ -8,6 +8,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -108,6 +111,66 @@ hipError_t upload_csr(const Sparse& M, DevCsr* D) {
   if ((e = upload(D->ptr, M.ptr.data(), M.ptr.size())) != hipSuccess) return e;
   if ((e = upload(D->idx, M.idx.data(), M.idx.size())) != hipSuccess) return e;
   return upload(D->val, M.val.data(), M.val.size());
+}
+
+// Setup on the device (K-Galerkin): AH = R (A P) for the linear interpolation pair from
+// CSR(A) that already sits on the device; AH stays there for the next level and is
+// copied to the host (the hierarchy's host copy, layout encoding, getters).
+hipError_t device_galerkin(const DevCsr& A, int64_t n_H, DevCsr* AH, Sparse* host) {
+  const int64_t n_h = A.n_rows;
+  hipError_t e;
+  DevMem cnt, bsum, total, ap_ptr, ap_idx, ap_val;
+  const int64_t nmax = std::max(n_h, n_H);
+  if ((e = cnt.alloc(sizeof(int32_t) * (nmax + 1))) != hipSuccess) return e;
+  if ((e = bsum.alloc(sizeof(int64_t) * ((nmax + 1023) / 1024 + 1))) != hipSuccess) return e;
+  if ((e = total.alloc(sizeof(int64_t))) != hipSuccess) return e;
+  auto scan = [&](int64_t n, DevMem& ptr, int64_t* tot) -> hipError_t {
+    hipError_t q;
+    if ((q = ptr.alloc(sizeof(int32_t) * (n + 1))) != hipSuccess) return q;
+    if ((q = launch_exclusive_scan(n, cnt.as<int32_t>(), ptr.as<int32_t>(), bsum.as<int64_t>(),
+                                   total.as<int64_t>(), nullptr)) != hipSuccess)
+      return q;
+    return hipMemcpy(tot, total.p, sizeof(int64_t), hipMemcpyDeviceToHost);
+  };
+  // A P
+  if ((e = launch_galerkin_ap(false, n_h, n_H, A.rowptr(), A.col(), A.v(), cnt.as<int32_t>(),
+                              nullptr, nullptr, nullptr, nullptr)) != hipSuccess)
+    return e;
+  int64_t nnz_ap = 0;
+  if ((e = scan(n_h, ap_ptr, &nnz_ap)) != hipSuccess) return e;
+  if (nnz_ap >= ((int64_t)1 << 31) - 1) return hipErrorInvalidValue;
+  if ((e = ap_idx.alloc(sizeof(int32_t) * std::max<int64_t>(nnz_ap, 1))) != hipSuccess) return e;
+  if ((e = ap_val.alloc(sizeof(double) * std::max<int64_t>(nnz_ap, 1))) != hipSuccess) return e;
+  if ((e = launch_galerkin_ap(true, n_h, n_H, A.rowptr(), A.col(), A.v(), nullptr,
+                              ap_ptr.as<int32_t>(), ap_idx.as<int32_t>(), ap_val.as<double>(),
+                              nullptr)) != hipSuccess)
+    return e;
+  // R (A P)
+  if ((e = launch_galerkin_rap(false, n_h, n_H, ap_ptr.as<int32_t>(), ap_idx.as<int32_t>(),
+                               ap_val.as<double>(), cnt.as<int32_t>(), nullptr, nullptr, nullptr,
+                               nullptr)) != hipSuccess)
+    return e;
+  int64_t nnz = 0;
+  if ((e = scan(n_H, AH->ptr, &nnz)) != hipSuccess) return e;
+  if (nnz >= ((int64_t)1 << 31) - 1) return hipErrorInvalidValue;
+  if ((e = AH->idx.alloc(sizeof(int32_t) * std::max<int64_t>(nnz, 1))) != hipSuccess) return e;
+  if ((e = AH->val.alloc(sizeof(double) * std::max<int64_t>(nnz, 1))) != hipSuccess) return e;
+  if ((e = launch_galerkin_rap(true, n_h, n_H, ap_ptr.as<int32_t>(), ap_idx.as<int32_t>(),
+                               ap_val.as<double>(), nullptr, AH->ptr.as<int32_t>(),
+                               AH->idx.as<int32_t>(), AH->val.as<double>(), nullptr)) != hipSuccess)
+    return e;
+  AH->n_rows = AH->n_cols = n_H;
+  AH->nnz = nnz;
+  host->n_outer = host->n_inner = n_H;
+  host->ptr.resize(n_H + 1);
+  host->idx.resize(nnz);
+  host->val.resize(nnz);
+  if ((e = hipMemcpy(host->ptr.data(), AH->ptr.p, sizeof(int32_t) * (n_H + 1), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+  if (nnz > 0) {
+    if ((e = hipMemcpy(host->idx.data(), AH->idx.p, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+    if ((e = hipMemcpy(host->val.data(), AH->val.p, sizeof(double) * nnz, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 // A level matrix on the device in one of the two layouts the kernels take.
@@ -678,6 +741,29 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     }
   }
 
+  // AMG_HIP_TIMING=1: wall time of the setup phases on stderr
+  struct PhaseTimer {
+    bool on = std::getenv("AMG_HIP_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::vector<std::pair<const char*, double>> acc;
+    void lap(const char* name) {
+      if (!on) return;
+      const auto t1 = std::chrono::steady_clock::now();
+      const double dt = std::chrono::duration<double>(t1 - t0).count();
+      t0 = t1;
+      for (auto& a : acc)
+        if (a.first == name) { a.second += dt; return; }
+      acc.emplace_back(name, dt);
+    }
+    ~PhaseTimer() {
+      if (!on) return;
+      std::fprintf(stderr, "amg_hip setup:");
+      for (auto& a : acc) std::fprintf(stderr, " %s %.2fs", a.first, a.second);
+      std::fprintf(stderr, "\n");
+    }
+  } timer;
+  static const char *T_IN = "input+transpose", *T_ENC = "encode+upload", *T_SM = "smoother-setup",
+                    *T_TR = "transfers", *T_RAP = "galerkin", *T_CSC = "csc-copy", *T_BAND = "band";
   const int nt = host_threads();
   s->lv.resize(n_levels);
   {
@@ -689,6 +775,9 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
   }
   // ---- hierarchy (multigrid.hpp:211-237) ----
   Sparse A_r = transpose(s->lv[0].A_csc);  // CSR(A_0)
+  DevCsr galerkin_A;             // CSR(A_l) on the device while the Galerkin chain runs there
+  bool galerkin_on_dev = false;
+  timer.lap(T_IN);
   for (int l = 0; l < n_levels; ++l) {
     Level& L = s->lv[l];
     L.symmetric = same_arrays(A_r, L.A_csc);
@@ -711,6 +800,7 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     HIP_TRY(hipMemset(L.u.p, 0, sizeof(double) * L.n));
     HIP_TRY(hipMemset(L.f.p, 0, sizeof(double) * L.n));
     HIP_TRY(hipMemset(L.r.p, 0, sizeof(double) * L.n));
+    timer.lap(T_ENC);
     // smoother-specific structures
     if (s->opt.smoother == AMG_HIP_SM_SPGS) {
       LexSchedule F, B;
@@ -752,6 +842,7 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     }  // dev
     if (!dev && s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS)
       greedy_coloring(L.A_csc, &L.color, &L.n_colors);
+    timer.lap(T_SM);
     if (l + 1 == n_levels) break;
     // ---- transfer operators for level l -> l+1 ----
     const int64_t n_h = L.n;
@@ -773,15 +864,30 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     }
     Sparse P_r = transpose(L.P_csc);  // CSR(P)
     Sparse R_r = transpose(L.R_csc);  // CSR(R)
-    if (dev) {
+    // the matrix-free kernels need no device copy of the linear operators
+    if (dev && !(L.linear && s->opt.stencil_transfers)) {
       HIP_TRY(upload_csr(P_r, &L.P_rows));
       HIP_TRY(upload_csr(R_r, &L.R_rows));
     }
-    // Galerkin (multigrid.hpp:219-223), row-major, Eigen's summation order
-    Sparse AH_r = galerkin_csr(R_r, A_r, P_r, nt);
+    timer.lap(T_TR);
+    // Galerkin (multigrid.hpp:219-223), row-major, Eigen's summation order: on the device
+    // for the linear interpolation pair (K-Galerkin), else on the host (same bits)
+    Sparse AH_r;
+    if (dev && L.linear && !s->opt.host_galerkin) {
+      if (!galerkin_on_dev) HIP_TRY(upload_csr(A_r, &galerkin_A));
+      DevCsr next;
+      HIP_TRY(device_galerkin(galerkin_A, n_H, &next, &AH_r));
+      galerkin_A = std::move(next);
+      galerkin_on_dev = true;
+    } else {
+      AH_r = galerkin_csr(R_r, A_r, P_r, nt);
+      galerkin_on_dev = false;
+    }
+    timer.lap(T_RAP);
     Level& C = s->lv[l + 1];
     C.n = n_H;
     C.A_csc = transpose(AH_r);
+    timer.lap(T_CSC);
     A_r.ptr.swap(AH_r.ptr);
     A_r.idx.swap(AH_r.idx);
     A_r.val.swap(AH_r.val);
@@ -818,6 +924,7 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     HIP_TRY(upload(s->band_b, S.sched_b.data(), S.sched_b.size()));
     HIP_TRY(upload(s->band_d, S.d.data(), S.d.size()));
   }
+  timer.lap(T_BAND);
   HIP_TRY(s->scratch.alloc(sizeof(double) * 1100));
   compute_bytes(s.get());
   HIP_TRY(hipDeviceSynchronize());

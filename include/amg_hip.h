@@ -97,7 +97,10 @@ typedef struct {
                               instead of n.  Same direct solve, different rounding
                               order: agrees with the sequential substitution to
                               ~1e-14 relative, not bit for bit.  Default 0.          */
-  int32_t reserved[2];
+  int32_t host_galerkin;   /* 1: build the Galerkin products R (A P) on the host instead of
+                              on the device (same entries, same bits; the device path
+                              is taken for LinearInterpolator operators only)        */
+  int32_t reserved[1];
   void* stream;            /* hipStream_t to run on; NULL (default) = the solver creates
                               and owns a non-blocking stream.  A caller that already
                               orders its device work on a stream (torch's current

@@ -238,6 +238,26 @@ def test_level_structure_bit_exact(amg, oracle):
         mg.close()
 
 
+def test_device_galerkin_matches_host_and_oracle(amg, oracle):
+    """K-Galerkin (R (A P) on the device for the linear interpolation pair) against the
+    host SpGEMM and the oracle: pattern incl. structural zeros, and values, bit for bit,
+    on every level; 2-D (odd and even line lengths) and 3-D."""
+    for n, dim, L in ((67, 2, 7), (64, 2, 6), (128, 2, 5), (13, 3, 6), (300, 2, 4)):
+        A, b = oracle.laplacian(n, dim=dim), oracle.rhs(n, dim=dim)
+        ref = oracle.Multigrid(A, b, L)
+        dev = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, omega=0.6)
+        host = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, omega=0.6, host_galerkin=True)
+        for l in range(L):
+            want = ref.level_matrix(l)
+            for mg in (dev, host):
+                cp, ri, va = mg.get_coefficient_matrix(l)
+                assert np.array_equal(cp, want.colptr), (n, dim, l)
+                assert np.array_equal(ri, want.rowind), (n, dim, l)
+                assert np.array_equal(va, want.val), (n, dim, l)
+        dev.close()
+        host.close()
+
+
 def test_vcycle_config1_bit_exact_and_golden(amg, oracle):
     """BASELINE config 1: 128^2, 3 levels, SparseGaussSeidel() (nu1=nu2=2 sweeps).
     GPU V-cycle == oracle V-cycle bit for bit, every level vector, 12 cycles;
