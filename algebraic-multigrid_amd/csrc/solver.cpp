@@ -384,7 +384,19 @@ struct Level {
   DevMem u, f, r, tmp;
   DevMem diag;             // a_ii (true-Jacobi smoother only)
   // transfers to level+1 (absent on the coarsest level)
-  Sparse P_csc, R_csc;
+  // host copies; for the built-in LinearInterpolator they are only materialised when a
+  // getter, the CSR transfer kernels or the host Galerkin product ask for them
+  mutable Sparse P_csc, R_csc;
+  bool lazy_linear = false;
+  int64_t n_coarse = 0;
+  const Sparse& P() const {
+    if (lazy_linear && P_csc.ptr.empty()) P_csc = linear_P(n, n_coarse);  // interpolator.hpp:106-129
+    return P_csc;
+  }
+  const Sparse& R() const {
+    if (lazy_linear && R_csc.ptr.empty()) R_csc = transpose(P());         // :132-134
+    return R_csc;
+  }
   bool linear = false;
   DevCsr P_rows, R_rows;   // CSR(P), CSR(R)
   // exact lexicographic schedules
@@ -858,14 +870,20 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
       if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
       L.linear = is_linear_P(L.P_csc, n_h, n_H) && same_arrays(transpose(L.P_csc), L.R_csc);
     } else {
-      L.P_csc = linear_P(n_h, n_H);          // interpolator.hpp:106-129
-      L.R_csc = transpose(L.P_csc);          // :132-134
+      L.lazy_linear = true;
+      L.n_coarse = n_H;
       L.linear = true;
     }
-    Sparse P_r = transpose(L.P_csc);  // CSR(P)
-    Sparse R_r = transpose(L.R_csc);  // CSR(R)
-    // the matrix-free kernels need no device copy of the linear operators
-    if (dev && !(L.linear && s->opt.stencil_transfers)) {
+    // the matrix-free kernels need no device copy of the linear operators, and the
+    // device Galerkin product no host copy
+    const bool dev_galerkin = dev && L.linear && !s->opt.host_galerkin;
+    const bool dev_rows = dev && !(L.linear && s->opt.stencil_transfers);
+    Sparse P_r, R_r;
+    if (dev_rows || !dev_galerkin) {
+      P_r = transpose(L.P());  // CSR(P)
+      R_r = transpose(L.R());  // CSR(R)
+    }
+    if (dev_rows) {
       HIP_TRY(upload_csr(P_r, &L.P_rows));
       HIP_TRY(upload_csr(R_r, &L.R_rows));
     }
@@ -873,7 +891,7 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     // Galerkin (multigrid.hpp:219-223), row-major, Eigen's summation order: on the device
     // for the linear interpolation pair (K-Galerkin), else on the host (same bits)
     Sparse AH_r;
-    if (dev && L.linear && !s->opt.host_galerkin) {
+    if (dev_galerkin) {
       if (!galerkin_on_dev) HIP_TRY(upload_csr(A_r, &galerkin_A));
       DevCsr next;
       HIP_TRY(device_galerkin(galerkin_A, n_H, &next, &AH_r));
@@ -1175,13 +1193,13 @@ amg_hip_status amg_hip_get_level_matrix(const amg_hip_solver* s, int32_t level,
 }
 int64_t amg_hip_get_transfer_nnz(const amg_hip_solver* s, int32_t level, int32_t which) {
   if (!s || level < 0 || level + 1 >= (int32_t)s->lv.size()) return -1;
-  return (which ? s->lv[level].R_csc : s->lv[level].P_csc).nnz();
+  return (which ? s->lv[level].R() : s->lv[level].P()).nnz();
 }
 amg_hip_status amg_hip_get_transfer(const amg_hip_solver* s, int32_t level, int32_t which,
                                     int32_t* colptr, int32_t* rowind, double* val) {
   if (!s || level < 0 || level + 1 >= (int32_t)s->lv.size())
     return fail(AMG_HIP_EINVAL, "level out of range");
-  const Sparse& M = which ? s->lv[level].R_csc : s->lv[level].P_csc;
+  const Sparse& M = which ? s->lv[level].R() : s->lv[level].P();
   if (colptr) std::memcpy(colptr, M.ptr.data(), sizeof(int32_t) * M.ptr.size());
   if (rowind) std::memcpy(rowind, M.idx.data(), sizeof(int32_t) * M.idx.size());
   if (val) std::memcpy(val, M.val.data(), sizeof(double) * M.val.size());
