@@ -6,10 +6,16 @@
 // arithmetic (separate IEEE multiply/add, true divide) is part of
 // the contract and several kernels are bit-exact against the CPU oracle.
 //
-// K-SELL (sell_kernel)      -- residual / true Jacobi / SpMV / rss terms / one colour
-//   of the multicolour GS on the solver's own matrices: CSR sliced into 64-row
+// K-Dict (dict_kernel, dict_resid_restrict_kernel, dict_jacobi_prolong_kernel,
+//   dict_gs_color_kernel)   -- residual / true Jacobi / SpMV / rss terms / one colour of
+//   the multicolour GS on dictionary-coded matrices: 8 or 16 bytes of byte codes per
+//   row into an LDS table of the matrix's distinct (column offset, value) pairs, and
+//   the forms fused across a level boundary (residual + restriction + first coarse
+//   sweep; last sweep + prolongation).  The default layout wherever a matrix qualifies.
+// K-SELL (sell_kernel)      -- the same operations on CSR sliced into 64-row
 //   lane-interleaved panels, 16-bit relative column indices, non-temporal matrix
-//   stream (see the comment at the kernel).  The fastest layout measured.
+//   stream (see the comment at the kernel).  Fallback layout; the fastest plain-CSR
+//   form measured.
 // K-CSR (csr_stage_kernel)  -- the same operations on plain CSR arrays (device-pointer
 //   API, custom interpolators, fallback when SELL would pad too much).
 //   One 256-thread workgroup owns 256 consecutive rows.  The workgroup's slice
@@ -26,6 +32,8 @@
 // K-GS-lex (gs_lex_window)  -- exact lexicographic Gauss-Seidel, dependency
 //   scheduled (parity mode, latency bound by construction).
 // K-Band   (band_solve)     -- coarsest-level banded LDL^T solve, one wave.
+// K-Spike  (spike_*)        -- the same solve partitioned over many waves (opt-in).
+// K-Galerkin (galerkin_*)   -- setup: R (A P) for the linear interpolation pair.
 // K-Halo / K-Gather         -- multi-GPU neighbour exchange and all-gather as
 //   graph-capturable kernels over hipIpc-mapped peer memory.
 // =============================================================================
