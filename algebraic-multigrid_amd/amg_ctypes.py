@@ -133,6 +133,7 @@ _SIGS = {
     "amg_hip_set_dict_rows": (None, [C.c_int32]),
     "amg_hip_set_xcd_mapping": (None, [C.c_int32]),
     "amg_hip_devmat_destroy": (None, [C.c_void_p]),
+    "amg_hip_devmat_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "amg_hip_devmat_apply": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_double, C.c_int64, C.c_void_p]),
     "amg_hip_dev_jacobi_from_zero": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

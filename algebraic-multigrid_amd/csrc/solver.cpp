@@ -1232,12 +1232,7 @@ amg_hip_status amg_hip_set_vec(amg_hip_solver* s, int32_t level, int32_t which,
 }
 int64_t amg_hip_coarse_halfbw(const amg_hip_solver* s) { return s ? s->band_w : -1; }
 
-amg_hip_status amg_hip_level_layout(const amg_hip_solver* s, int32_t level, int32_t* layout,
-                                    int64_t* matrix_stream_bytes) {
-  if (!s || level < 0 || level >= (int32_t)s->lv.size())
-    return fail(AMG_HIP_EINVAL, "level out of range");
-  if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "host_only solver has no device matrices");
-  const DevMat& A = s->lv[level].A_rows;
+static void layout_of(const DevMat& A, int32_t* layout, int64_t* matrix_stream_bytes) {
   int32_t lay;
   int64_t bytes;
   if (A.dict) {
@@ -1252,6 +1247,13 @@ amg_hip_status amg_hip_level_layout(const amg_hip_solver* s, int32_t level, int3
   }
   if (layout) *layout = lay;
   if (matrix_stream_bytes) *matrix_stream_bytes = bytes;
+}
+amg_hip_status amg_hip_level_layout(const amg_hip_solver* s, int32_t level, int32_t* layout,
+                                    int64_t* matrix_stream_bytes) {
+  if (!s || level < 0 || level >= (int32_t)s->lv.size())
+    return fail(AMG_HIP_EINVAL, "level out of range");
+  if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "host_only solver has no device matrices");
+  layout_of(s->lv[level].A_rows, layout, matrix_stream_bytes);
   return AMG_HIP_OK;
 }
 
@@ -1833,6 +1835,13 @@ amg_hip_status amg_hip_devmat_create(int64_t nrows, int64_t ncols, const int32_t
   d->diag_shift = diag_shift;
   HIP_TRY(upload_mat_pruned(M, layout, true, &d->m, diag_shift));
   *out = reinterpret_cast<amg_hip_devmat*>(d.release());
+  return AMG_HIP_OK;
+}
+amg_hip_status amg_hip_devmat_layout(const amg_hip_devmat* h, int32_t* layout,
+                                     int64_t* matrix_stream_bytes) {
+  auto* d = reinterpret_cast<const amg_hip_devmat_impl*>(h);
+  if (!d) return fail(AMG_HIP_EINVAL, "bad argument");
+  layout_of(d->m, layout, matrix_stream_bytes);
   return AMG_HIP_OK;
 }
 void amg_hip_devmat_destroy(amg_hip_devmat* h) {

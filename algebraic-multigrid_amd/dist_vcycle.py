@@ -136,7 +136,8 @@ class HipBackend:
         return t.detach().cpu().numpy()
 
     def matrix(self, rowptr, col, val, ncols=None, diag_shift=0):
-        """Upload a local CSR block in the library's device layout (SELL-64 panels)."""
+        """Upload a local CSR block in the library's device layout (dictionary-coded when
+        the block qualifies, else SELL-64 panels)."""
         import ctypes as C
         rowptr = np.ascontiguousarray(rowptr, np.int32)
         col = np.ascontiguousarray(col, np.int32)
@@ -152,6 +153,13 @@ class HipBackend:
         self._mats = getattr(self, "_mats", [])
         self._mats.append(h)
         return h
+
+    def matrix_layout(self, m):
+        """(layout name, matrix stream bytes) of an uploaded block."""
+        import ctypes as C
+        lay, nb = C.c_int32(0), C.c_int64(0)
+        self._chk(self.lib.amg_hip_devmat_layout(m, C.byref(lay), C.byref(nb)))
+        return {1: "csr", 2: "sell", 3: "dict"}.get(lay.value, "?"), int(nb.value)
 
     def _chk(self, st):
         if st != 0:
@@ -795,16 +803,28 @@ class DistributedVcycle:
 
 
 # --------------------------------------------------------------------- bench ---
-def _result_line(args, world, L, dv, results, best, notes, rehearsal, avg_ms, sweep_bytes, t0):
+def _result_line(args, world, L, dv, results, best, notes, rehearsal, avg_ms, sweep_bytes, t0,
+                 layout=None):
     from bench import HBM_PEAK_GBS
     dt, rss0, rss = results[best]
     roof = None
     if avg_ms:
         achieved = sweep_bytes / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "sell_kernel<CSR_JACOBI> (rank 0 level-0 Jacobi sweep, SELL-64 panels)",
+        lay, mat_bytes, rows = layout if layout else ("?", None, None)
+        kern = {"dict": "dict_kernel<CSR_JACOBI> (dictionary-coded rows)",
+                "sell": "sell_kernel<CSR_JACOBI> (SELL-64 panels)",
+                "csr": "csr_stage_kernel<CSR_JACOBI> (LDS-staged CSR)"}.get(lay, "Jacobi sweep")
+        fmt = (mat_bytes + 24 * rows) if mat_bytes is not None else None
+        roof = {"bound": "hbm", "kernel": f"{kern}: rank 0's row block of the level-0 Jacobi sweep",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_ms}
+                "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_ms,
+                "layout": lay, "format_bytes_per_launch": fmt,
+                "format_GBps": (fmt / (avg_ms * 1e-3) / 1e9) if fmt else None,
+                "note": "achieved/frac use the CSR-formula bytes (12 nnz + 28 n) of the rank's row "
+                        "block; the dictionary-coded layout moves format_bytes_per_launch, so frac "
+                        "can exceed 1 (see the N=1 line for the PMC-measured traffic)"}
+    n_dist = notes.get(best + "_distributed_levels", dv.n_dist)   # of the reported transport
     return {
         "metric": "V-cycles/sec, 2D Poisson N=4096^2 (fine-grid smoother HBM GB/s under roofline)",
         "value": args.steps / dt, "unit": "V-cycles/s", "n_gpus": world,
@@ -814,9 +834,9 @@ def _result_line(args, world, L, dv, results, best, notes, rehearsal, avg_ms, sw
         "config": {
             "workload": (f"2D 5-point Poisson {args.n}x{args.n} (Grid::laplacian/rhs), true Jacobi "
                          f"omega={args.omega} {args.sweeps}+{args.sweeps} sweeps, {L}-level V-cycle, "
-                         f"row-block shards over {world} GPUs ({dv.n_dist} distributed levels, "
+                         f"row-block shards over {world} GPUs ({n_dist} distributed levels, "
                          f"rest agglomerated), fp64"),
-            "n": args.n, "levels": L, "distributed_levels": dv.n_dist, "rehearsal": rehearsal,
+            "n": args.n, "levels": L, "distributed_levels": n_dist, "rehearsal": rehearsal,
             "dist_min_rows": args.dist_min_rows, "setup_seconds": time.time() - t0,
             "halo_exchange": best, "exchange_modes": notes,
             "vcycles_per_sec_by_exchange": {k: args.steps / v[0] for k, v in results.items()},
@@ -892,17 +912,20 @@ def bench(args):
         import threading
         stash["json"] = _json.dumps(_result_line(args, world, L, dv, results, "p2p", {"note": "alternative exchange hung"},
                                                  rehearsal, None, None, t0)) if rank == 0 else None
-        modes = ["ipc", "graph"] if args.comm == "auto" else [args.comm]
-        for mode in modes:
+        # cheaper exchanges pay off on smaller levels (results do not depend on the
+        # threshold); the in-graph exchange is timed with two thresholds because the
+        # cost of a flag round trip over xGMI cannot be rehearsed on one GPU
+        cand = {"ipc": [("ipc", args.dist_min_rows_ipc)],
+                "graph": [("graph", args.dist_min_rows_graph), ("graph@8x", 8 * args.dist_min_rows_graph)]}
+        modes = cand["ipc"] + cand["graph"] if args.comm == "auto" else cand[args.comm]
+        for mode, min_rows in modes:
             dog = threading.Timer(args.comm_timeout, bail)
             dog.daemon = True
             dog.start()
             try:
-                # cheaper exchanges pay off on smaller levels (results do not depend on it)
-                min_rows = args.dist_min_rows_ipc if mode == "ipc" else args.dist_min_rows_graph
                 dvx = DistributedVcycle(hier, b, be, rank, world, omega=args.omega,
                                         sweeps=args.sweeps, dist_min_rows=min_rows,
-                                        host_staged=rehearsal, comm=mode)
+                                        host_staged=rehearsal, comm=mode.split("@")[0])
                 notes[mode + "_distributed_levels"] = dvx.n_dist
                 res = timed(dvx)
                 same = (res[1] == results["p2p"][1]) and (res[2] == results["p2p"][2]) and not dvx.timed_out()
@@ -941,7 +964,12 @@ def bench(args):
     if rank == 0:
         if args.warmup >= 1 and not (rss < rss0):
             raise SystemExit(f"V-cycle iteration is not converging (rss {rss0:.3e} -> {rss:.3e})")
-        out = _result_line(args, world, L, dv, results, best, notes, rehearsal, avg_ms, sweep_bytes, t0)
+        lay = None
+        if D is not None:
+            name, mat_bytes = be.matrix_layout(D.mat)
+            lay = (name, mat_bytes, D.e - D.s)
+        out = _result_line(args, world, L, dv, results, best, notes, rehearsal, avg_ms, sweep_bytes, t0,
+                           layout=lay)
     dist.barrier()
     dist.destroy_process_group()
     return out

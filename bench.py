@@ -206,11 +206,11 @@ def main():
                          "direct hipIpc pushes with stream memory ops; graph = pushes + flags as "
                          "kernels, one hipGraph per rank; auto = time all, keep the fastest that "
                          "reproduces the p2p result bit for bit")
-    ap.add_argument("--dist-min-rows-ipc", type=int, default=2000000)
+    ap.add_argument("--dist-min-rows-ipc", type=int, default=5000000)
     ap.add_argument("--dist-min-rows-graph", type=int, default=250000)
     ap.add_argument("--comm-timeout", type=float, default=180.0,
                     help="seconds after which a hung alternative exchange mode is abandoned")
-    ap.add_argument("--dist-min-rows", type=int, default=6000000,
+    ap.add_argument("--dist-min-rows", type=int, default=10000000,
                     help="multi-GPU: levels with fewer rows (in total) run redundantly on every rank")
     args = ap.parse_args()
 

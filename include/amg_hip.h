@@ -341,7 +341,8 @@ amg_hip_status amg_hip_dev_spmv(int64_t nrows, int64_t nnz, int32_t max_block_nn
                                 const int32_t* col, const double* val,
                                 const double* v, double* out, void* stream);
 /* The same three operations on a matrix the LIBRARY uploads in its own device
- * layout (SELL-64 panels unless `layout` says otherwise; exact zeros dropped):
+ * layout (amg_hip_layout; AUTO = dictionary-coded when the block qualifies, else
+ * SELL-64 panels; exact zeros dropped):
  * rows x cols local CSR block given on the host, columns indexing the vector the
  * operation is applied to.  op: 0 = residual (out = f - A x), 1 = Jacobi sweep
  * (diagonal of row i at column i + diag_shift), 2 = SpMV (f unused).  The
@@ -352,6 +353,9 @@ amg_hip_status amg_hip_devmat_create(int64_t nrows, int64_t ncols, const int32_t
                                      const int32_t* col, const double* val, int32_t layout,
                                      int64_t diag_shift, int32_t device, amg_hip_devmat** out);
 void amg_hip_devmat_destroy(amg_hip_devmat* m);
+/* Layout the block was uploaded in and its matrix stream bytes (amg_hip_level_layout). */
+amg_hip_status amg_hip_devmat_layout(const amg_hip_devmat* m, int32_t* layout,
+                                     int64_t* matrix_stream_bytes);
 amg_hip_status amg_hip_devmat_apply(const amg_hip_devmat* m, int32_t op, const double* x,
                                     const double* f, double* out, double omega,
                                     int64_t diag_shift, void* stream);
