@@ -171,6 +171,30 @@ def run_single(args):
         },
     }
     mg.close()
+    # the same workload with the level matrices as plain CSR panels (SELL-64, the layout the
+    # CSR-formula bytes describe): a second, shorter measurement in the same run
+    if lay_name == "dict" and args.smoother == "jacobi" and not args.no_csr_ref:
+        colptr, rowind, val = amg.laplacian(args.n)
+        ref = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_JACOBI, smoother_iters=args.sweeps,
+                            omega=args.omega, use_graph=not args.no_graph, layout=amg.LAYOUT_SELL)
+        del colptr, rowind, val
+        ref.vcycle(args.warmup)
+        ref.sync()
+        t2 = time.perf_counter()
+        k = max(10, args.steps // 2)
+        ref.vcycle(k)
+        ref.sync()
+        dt2 = time.perf_counter() - t2
+        ref_ms, _ = ref.profile_fine_sweep(max(8, args.profile_launches // 2))
+        rss_ref = ref.rss()
+        ref.close()
+        out["config"]["csr_layout_reference"] = {
+            "layout": "sell (CSR sliced into 64-row panels, 16-bit relative columns)",
+            "vcycles_per_sec": k / dt2, "ms_per_step": dt2 / k * 1e3, "steps": k,
+            "fine_sweep_ms": ref_ms, "fine_sweep_GBps": sweep_bytes / (ref_ms * 1e-3) / 1e9,
+            "fine_sweep_frac_of_peak": sweep_bytes / (ref_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "rss_after_warmup_plus_steps": rss_ref,
+        }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args)
     return out
@@ -198,6 +222,8 @@ def main():
     ap.add_argument("--fast-coarse", action="store_true",
                     help="partitioned (parallel) coarse solve; then fewer levels pay off (--levels 13)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-csr-ref", action="store_true",
+                    help="skip the second measurement with the plain-CSR (SELL-64) layout")
     ap.add_argument("--cpu-n", type=int, default=2048, help="grid of the CPU baseline sample")
     ap.add_argument("--cpu-cycles", type=int, default=5)
     ap.add_argument("--profile-launches", type=int, default=40)
