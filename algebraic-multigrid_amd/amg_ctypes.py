@@ -132,6 +132,7 @@ _SIGS = {
     "amg_hip_set_nontemporal": (None, [C.c_int32]),
     "amg_hip_set_dict_rows": (None, [C.c_int32]),
     "amg_hip_set_xcd_mapping": (None, [C.c_int32]),
+    "amg_hip_set_row_types": (None, [C.c_int32]),
     "amg_hip_devmat_destroy": (None, [C.c_void_p]),
     "amg_hip_devmat_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "amg_hip_devmat_apply": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -213,6 +214,10 @@ def set_index16(on):
 
 def set_dict_rows(rows_per_lane):
     lib().amg_hip_set_dict_rows(int(rows_per_lane))
+
+
+def set_row_types(on):
+    lib().amg_hip_set_row_types(int(on))
 
 
 def set_xcd_mapping(on):

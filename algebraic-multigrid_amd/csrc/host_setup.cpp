@@ -260,6 +260,38 @@ bool to_dict(const Sparse& M, int64_t diag_shift, DictMat* D, const int32_t* row
     D->codes[(size_t)r * D->words] = w[0];
     if (D->words == 2) D->codes[(size_t)r * 2 + 1] = w[1];
   }
+  // row types
+  D->rtype.assign((size_t)n, 255);
+  D->rwords.assign((size_t)256 * D->words, ~(uint64_t)0);
+  std::map<std::pair<uint64_t, uint64_t>, int> types;
+  int last = -1;
+  std::pair<uint64_t, uint64_t> last_key(0, 0);
+  for (int64_t r = 0; r < n; ++r) {
+    const std::pair<uint64_t, uint64_t> key(D->codes[(size_t)r * D->words],
+                                            D->words == 2 ? D->codes[(size_t)r * 2 + 1] : 0);
+    int t;
+    if (last >= 0 && key == last_key) {
+      t = last;
+    } else {
+      auto it = types.find(key);
+      if (it == types.end()) {
+        if (types.size() >= 255) {  // too many distinct rows: first level only
+          D->rtype.clear();
+          D->rwords.clear();
+          return true;
+        }
+        t = (int)types.size();
+        types.emplace(key, t);
+        D->rwords[(size_t)t * D->words] = key.first;
+        if (D->words == 2) D->rwords[(size_t)t * 2 + 1] = key.second;
+      } else {
+        t = it->second;
+      }
+      last = t;
+      last_key = key;
+    }
+    D->rtype[(size_t)r] = (uint8_t)t;
+  }
   return true;
 }
 

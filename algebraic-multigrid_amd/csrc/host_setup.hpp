@@ -75,6 +75,10 @@ struct DictMat {
   std::vector<uint64_t> codes;  // n * words
   std::vector<int32_t> doff;    // table: column offset from the row's diagonal column
   std::vector<double> dval;     // table: value
+  // second level: when the rows repeat as whole code words (<= 255 distinct), one byte
+  // per row into a word table of 256 * words entries (entry 255 = empty row, all 0xFF)
+  std::vector<uint8_t> rtype;   // n, empty when the matrix has more distinct rows
+  std::vector<uint64_t> rwords; // 256 * words
 };
 // false when the matrix does not qualify (more than 255 pairs or a row > 16 entries).
 // rowid (optional): dof of every storage row (colour-permuted copies; -1 = empty padding

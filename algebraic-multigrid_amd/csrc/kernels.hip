@@ -418,15 +418,21 @@ static int g_xcd_map = 1;
 // many bytes are in flight per wave (the launcher checks the 16-byte alignment).
 // (Persistent workgroups that prefetch their next tile were measured 10 % SLOWER on the
 // 4096^2 fine level, 108 vs 99 us, and are not kept.)
+// Row types (second-level dictionary): the rows of such a matrix also repeat as whole
+// code words (2-D Poisson hierarchy: <= 12 distinct rows per level, 3-D: <= 40), so
+// when there are at most 255 distinct words a row is ONE byte indexing a word table in
+// LDS (type 255 = empty row), and the matrix stream is 1 byte per row.
 template <int WORDS, int R>
 struct DictStream {  // streamed operands of R rows of one lane
   uint64_t cw[R][2];
+  uint32_t ty;  // row types, byte r = row r
   double fi[R], xi[R];
   bool live[R];
 };
 template <int MODE, int WORDS, bool NT, int R>
 __device__ __forceinline__ void dict_fetch(DictStream<WORDS, R>& s, int row0, int n,
                                            const uint64_t* __restrict__ codes,
+                                           const uint8_t* __restrict__ rtype,
                                            const double* __restrict__ f, const double* x,
                                            int dshift) {
   typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
@@ -437,14 +443,19 @@ __device__ __forceinline__ void dict_fetch(DictStream<WORDS, R>& s, int row0, in
     s.cw[r][0] = s.cw[r][1] = ~(uint64_t)0;
     s.fi[r] = s.xi[r] = 0.0;
   }
+  s.ty = 0xFFFFu;  // both rows empty; unpacked in dict_expand, after the other loads are out
   if (R == 2 && s.live[R - 1]) {
-    const u64x2* vp = reinterpret_cast<const u64x2*>(codes + (int64_t)row0 * WORDS);
-    const u64x2 a = NT ? __builtin_nontemporal_load(vp) : *vp;
-    if (WORDS == 2) {
-      const u64x2 b2 = NT ? __builtin_nontemporal_load(vp + 1) : vp[1];
-      s.cw[0][0] = a.x; s.cw[0][1] = a.y; s.cw[R - 1][0] = b2.x; s.cw[R - 1][1] = b2.y;
+    if (rtype) {  // wave-uniform
+      s.ty = *reinterpret_cast<const uint16_t*>(rtype + row0);
     } else {
-      s.cw[0][0] = a.x; s.cw[R - 1][0] = a.y;
+      const u64x2* vp = reinterpret_cast<const u64x2*>(codes + (int64_t)row0 * WORDS);
+      const u64x2 a = NT ? __builtin_nontemporal_load(vp) : *vp;
+      if (WORDS == 2) {
+        const u64x2 b2 = NT ? __builtin_nontemporal_load(vp + 1) : vp[1];
+        s.cw[0][0] = a.x; s.cw[0][1] = a.y; s.cw[R - 1][0] = b2.x; s.cw[R - 1][1] = b2.y;
+      } else {
+        s.cw[0][0] = a.x; s.cw[R - 1][0] = a.y;
+      }
     }
     if (MODE != CSR_SPMV) {
       const f64x2* fp = reinterpret_cast<const f64x2*>(f + row0);
@@ -453,17 +464,34 @@ __device__ __forceinline__ void dict_fetch(DictStream<WORDS, R>& s, int row0, in
     }
     if (MODE == CSR_JACOBI) { s.xi[0] = x[row0 + dshift]; s.xi[R - 1] = x[row0 + 1 + dshift]; }
   } else if (s.live[0]) {
-    const uint64_t* cp = codes + (int64_t)row0 * WORDS;
-    if (WORDS == 2) {
-      const u64x2* vp = reinterpret_cast<const u64x2*>(cp);
-      const u64x2 t = NT ? __builtin_nontemporal_load(vp) : *vp;
-      s.cw[0][0] = t.x; s.cw[0][1] = t.y;
+    if (rtype) {
+      s.ty = 0xFF00u | rtype[row0];
     } else {
-      s.cw[0][0] = NT ? __builtin_nontemporal_load(cp) : cp[0];
+      const uint64_t* cp = codes + (int64_t)row0 * WORDS;
+      if (WORDS == 2) {
+        const u64x2* vp = reinterpret_cast<const u64x2*>(cp);
+        const u64x2 t = NT ? __builtin_nontemporal_load(vp) : *vp;
+        s.cw[0][0] = t.x; s.cw[0][1] = t.y;
+      } else {
+        s.cw[0][0] = NT ? __builtin_nontemporal_load(cp) : cp[0];
+      }
     }
     if (MODE != CSR_SPMV) s.fi[0] = NT ? __builtin_nontemporal_load(f + row0) : f[row0];
     if (MODE == CSR_JACOBI) s.xi[0] = x[row0 + dshift];
   }
+}
+// word table of the row types: 256 entries of WORDS words, entry 255 = all 0xFF (host pads)
+template <int WORDS>
+__device__ __forceinline__ void dict_stage_words(uint64_t* wtab, const uint64_t* __restrict__ rwords) {
+#pragma unroll
+  for (int k = 0; k < WORDS; ++k) wtab[threadIdx.x * WORDS + k] = rwords[threadIdx.x * WORDS + k];
+}
+template <int WORDS, int R>
+__device__ __forceinline__ void dict_expand(DictStream<WORDS, R>& s, const uint64_t* wtab) {
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int k = 0; k < WORDS; ++k) s.cw[r][k] = wtab[((s.ty >> (8 * r)) & 0xFFu) * WORDS + k];
 }
 // One 32-byte LDS entry per code.  Entry 255 (= no entry) is all zero: its gather reads
 // the row's diagonal column (always a valid address).
@@ -550,10 +578,16 @@ __device__ __forceinline__ void dict_rows(const DictStream<WORDS, R>& s, int row
     }
     if (MODE == CSR_RESID || MODE == CSR_SPMV) {
       res[r] = acc;
-    } else if (MODE == CSR_JACOBI) {
-      res[r] = (diag == 0.0) ? s.xi[r] : s.xi[r] + omega * ((s.fi[r] - acc) / diag - s.xi[r]);
-    } else if (MODE == CSR_GS) {
-      res[r] = (diag == 0.0) ? s.xi[r] : (s.fi[r] - acc) / diag;  // smoother.hpp:136
+    } else if (MODE == CSR_JACOBI || MODE == CSR_GS) {
+      // The division runs for every row (a missing diagonal divides by 1 and is then
+      // discarded): with it inside `diag != 0` clang puts the whole row walk, gathers and
+      // their waits included, into that branch and the rows of a lane run one after
+      // the other instead of overlapping.
+      const bool nod = diag == 0.0;
+      double q = (s.fi[r] - acc) / (nod ? 1.0 : diag);  // smoother.hpp:136
+      asm volatile("" : "+v"(q));
+      if (MODE == CSR_GS) res[r] = nod ? s.xi[r] : q;
+      else res[r] = nod ? s.xi[r] : s.xi[r] + omega * (q - s.xi[r]);
     } else {
       const double d = s.fi[r] - acc;
       res[r] = d * d;
@@ -585,17 +619,23 @@ __device__ __forceinline__ int xcd_tile(unsigned b, unsigned nb, int on) {
   const unsigned k = b & 7u, i = b >> 3, q = nb >> 3, r = nb & 7u;
   return (int)(k * q + (k < r ? k : r) + i);
 }
+// (Two tiles per workgroup, i.e. the streamed operands of twice as many rows in flight per
+// lane, measured SLOWER on the 4096^2 fine level: 99.5 vs 86.8 us, 90 VGPRs.)
 template <int MODE, int WORDS, int UN, bool NT, int R>
 __global__ __launch_bounds__(256) void dict_kernel(
-    int n, const uint64_t* __restrict__ codes, const int32_t* __restrict__ doff,
+    int n, const uint64_t* __restrict__ codes, const uint8_t* __restrict__ rtype,
+    const uint64_t* __restrict__ rwords, const int32_t* __restrict__ doff,
     const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
     double* out, double omega, int dshift, int xcd_map) {
   __shared__ DictEntry tab[256];
+  __shared__ uint64_t wtab[256 * WORDS];
   const int row0 = (xcd_tile(blockIdx.x, gridDim.x, xcd_map) * 256 + (int)threadIdx.x) * R;
   DictStream<WORDS, R> s;
-  dict_fetch<MODE, WORDS, NT, R>(s, row0, n, codes, f, x, dshift);  // in flight while the table is staged
+  dict_fetch<MODE, WORDS, NT, R>(s, row0, n, codes, rtype, f, x, dshift);  // in flight while the tables are staged
   dict_stage_table<MODE>(tab, doff, dval, ntab);
+  if (rtype) dict_stage_words<WORDS>(wtab, rwords);
   __syncthreads();
+  if (rtype) dict_expand<WORDS, R>(s, wtab);
   double res[R];
   dict_rows<MODE, WORDS, UN, R>(s, row0, tab, x, omega, dshift, res);
   dict_store<WORDS, NT, R>(s, row0, res, out);
@@ -615,18 +655,22 @@ __global__ __launch_bounds__(256) void dict_kernel(
 // Other smoothers (uH1 == nullptr): the coarse u is zero-filled instead (uH0, :278).
 template <int WORDS, int UN, bool NT, int R>
 __global__ __launch_bounds__(256) void dict_resid_restrict_kernel(
-    int n, const uint64_t* __restrict__ codes, const int32_t* __restrict__ doff,
+    int n, const uint64_t* __restrict__ codes, const uint8_t* __restrict__ rtype,
+    const uint64_t* __restrict__ rwords, const int32_t* __restrict__ doff,
     const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
     double* r_out, int nH, double* __restrict__ fH, const double* __restrict__ diagH,
     double* __restrict__ uH1, double* __restrict__ uH0, double omega, int xcd_map) {
   __shared__ DictEntry tab[256];
+  __shared__ uint64_t wtab[256 * WORDS];
   __shared__ double rs[256 * R];
   const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
   const int row0 = tile * (256 * R - 2) + (int)threadIdx.x * R;
   DictStream<WORDS, R> s;
-  dict_fetch<CSR_RESID, WORDS, NT, R>(s, row0, n, codes, f, x, 0);
+  dict_fetch<CSR_RESID, WORDS, NT, R>(s, row0, n, codes, rtype, f, x, 0);
   dict_stage_table<CSR_RESID>(tab, doff, dval, ntab);
+  if (rtype) dict_stage_words<WORDS>(wtab, rwords);
   __syncthreads();
+  if (rtype) dict_expand<WORDS, R>(s, wtab);
   double res[R];
   dict_rows<CSR_RESID, WORDS, UN, R>(s, row0, tab, x, omega, 0, res);
   dict_store<WORDS, NT, R>(s, row0, res, r_out);
@@ -656,19 +700,23 @@ __global__ __launch_bounds__(256) void dict_resid_restrict_kernel(
 // u_h[2j] += 0.5 u_H[j-1] + 0.5 u_H[j], u_h[2j+1] += u_H[j] (linear_prolong_add2_kernel).
 template <int WORDS, int UN, bool NT, int R>
 __global__ __launch_bounds__(256) void dict_jacobi_prolong_kernel(
-    int n, const uint64_t* __restrict__ codes, const int32_t* __restrict__ doff,
+    int n, const uint64_t* __restrict__ codes, const uint8_t* __restrict__ rtype,
+    const uint64_t* __restrict__ rwords, const int32_t* __restrict__ doff,
     const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
     double* out, double omega, int n_h, double* uh, int xcd_map) {
   typedef double f64x2 __attribute__((ext_vector_type(2)));
   __shared__ DictEntry tab[256];
+  __shared__ uint64_t wtab[256 * WORDS];
   __shared__ double rs[256 * R];
   const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
   const int stride = 256 * R - 2;
   const int row0 = tile * stride + (int)threadIdx.x * R;
   DictStream<WORDS, R> s;
-  dict_fetch<CSR_JACOBI, WORDS, NT, R>(s, row0, n, codes, f, x, 0);
+  dict_fetch<CSR_JACOBI, WORDS, NT, R>(s, row0, n, codes, rtype, f, x, 0);
   dict_stage_table<CSR_JACOBI>(tab, doff, dval, ntab);
+  if (rtype) dict_stage_words<WORDS>(wtab, rwords);
   __syncthreads();
+  if (rtype) dict_expand<WORDS, R>(s, wtab);
   double res[R];
   dict_rows<CSR_JACOBI, WORDS, UN, R>(s, row0, tab, x, omega, 0, res);
   dict_store<WORDS, NT, R>(s, row0, res, out);
@@ -702,45 +750,6 @@ __global__ __launch_bounds__(256) void dict_jacobi_prolong_kernel(
   }
 }
 
-template <int MODE, int WORDS, int UN>
-static hipError_t launch_dict_u(int64_t n, bool nt, const uint64_t* codes, const int32_t* doff,
-                                const double* dval, int ntab, const double* x, const double* f,
-                                double* out, double omega, int64_t dshift, hipStream_t st) {
-  // two rows per lane need 16-byte aligned f / out / codes (vector lane accesses)
-  const bool two = g_dict_rows_per_lane == 2 && n >= 4096 &&
-                   ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(out) |
-                     reinterpret_cast<uintptr_t>(codes)) & 15) == 0;
-  const int rr = two ? 2 : 1;
-  const int64_t tiles = (n + 256 * rr - 1) / (256 * rr);
-#define AMG_DICT_GO(NTF, RR)                                                                     \
-  hipLaunchKernelGGL((dict_kernel<MODE, WORDS, UN, NTF, RR>), dim3((unsigned)tiles), dim3(256), 0, \
-                     st, (int)n, codes, doff, dval, ntab, x, f, out, omega, (int)dshift, g_xcd_map)
-  if (two) {
-    if (nt) AMG_DICT_GO(true, 2); else AMG_DICT_GO(false, 2);
-  } else {
-    if (nt) AMG_DICT_GO(true, 1); else AMG_DICT_GO(false, 1);
-  }
-#undef AMG_DICT_GO
-  return hipGetLastError();
-}
-template <int MODE>
-static hipError_t launch_dict_mode(int64_t n, int words, int wmax, bool nt, const uint64_t* codes,
-                                   const int32_t* doff, const double* dval, int ntab,
-                                   const double* x, const double* f, double* out, double omega,
-                                   int64_t dshift, hipStream_t st) {
-#define AMG_DICT(W, U) \
-  return launch_dict_u<MODE, W, U>(n, nt, codes, doff, dval, ntab, x, f, out, omega, dshift, st)
-  if (words == 1) {
-    if (wmax <= 3) AMG_DICT(1, 3);
-    if (wmax <= 5) AMG_DICT(1, 5);
-    if (wmax <= 7) AMG_DICT(1, 7);
-    AMG_DICT(1, 8);
-  }
-  if (wmax <= 9) AMG_DICT(2, 9);
-  if (wmax <= 12) AMG_DICT(2, 12);
-  AMG_DICT(2, 16);
-#undef AMG_DICT
-}
 // ---- one colour of the multicolour Gauss-Seidel sweep, dictionary-coded -----------------
 // Storage rows [p0, p0 + count) are the rows of one colour (host_setup.hpp: ColorPerm),
 // rowid[p] the dof each one updates (-1 = padding); codes are indexed by storage row,
@@ -759,6 +768,7 @@ __global__ __launch_bounds__(256) void dict_gs_color_kernel(
   DictStream<WORDS, 1> s;
   s.live[0] = row >= 0;
   s.cw[0][0] = s.cw[0][1] = ~(uint64_t)0;
+  s.ty = 0xFFFFu;
   s.fi[0] = s.xi[0] = 0.0;
   if (s.live[0]) {
     const uint64_t* cp = codes + (int64_t)p * WORDS;
@@ -836,59 +846,69 @@ static bool aligned16(const void* a, const void* b, const void* c) {
   return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
            reinterpret_cast<uintptr_t>(c)) & 15) == 0;
 }
-hipError_t launch_dict_resid_restrict(int64_t n, int words, int wmax, int nt,
-                                      const uint64_t* codes, const int32_t* doff,
-                                      const double* dval, int ntab, const double* x,
+// two rows per lane need 16-byte aligned f / out / codes (vector lane accesses)
+static bool dict_two_rows(int64_t n, const DictRef& D, const void* f, const void* out) {
+  return g_dict_rows_per_lane == 2 && n >= 4096 && aligned16(f, out, D.rtype ? nullptr : D.codes) &&
+         (!D.rtype || (reinterpret_cast<uintptr_t>(D.rtype) & 1) == 0);
+}
+hipError_t launch_dict_resid_restrict(int64_t n, const DictRef& D, const double* x,
                                       const double* f, double* r_out, int64_t nH, double* fH,
                                       const double* diagH, double* uH1, double* uH0,
                                       double omega, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  if (!dict_args_ok(n, words, wmax, ntab) || nH > n || !fH || (uH1 ? !diagH : !uH0))
+  if (!dict_args_ok(n, D.words, D.wmax, D.ntab) || nH > n || !fH || (uH1 ? !diagH : !uH0))
     return hipErrorInvalidValue;
-  const bool two = g_dict_rows_per_lane == 2 && n >= 4096 && aligned16(f, r_out, codes);
+  const bool two = dict_two_rows(n, D, f, r_out);
   const int64_t stride = 256 * (two ? 2 : 1) - 2;
   const unsigned tiles = (unsigned)((n + stride - 1) / stride);
-  return dict_dispatch(words, wmax, nt != 0, two, [&](auto W, auto U, auto NTF, auto RR) {
+  return dict_dispatch(D.words, D.wmax, D.nt != 0, two, [&](auto W, auto U, auto NTF, auto RR) {
     hipLaunchKernelGGL((dict_resid_restrict_kernel<decltype(W)::value, decltype(U)::value,
                                                    decltype(NTF)::value, decltype(RR)::value>),
-                       dim3(tiles), dim3(256), 0, st, (int)n, codes, doff, dval, ntab, x, f, r_out,
-                       (int)nH, fH, diagH, uH1, uH0, omega, g_xcd_map);
+                       dim3(tiles), dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff,
+                       D.dval, D.ntab, x, f, r_out, (int)nH, fH, diagH, uH1, uH0, omega, g_xcd_map);
   });
 }
-hipError_t launch_dict_jacobi_prolong(int64_t n, int words, int wmax, int nt,
-                                      const uint64_t* codes, const int32_t* doff,
-                                      const double* dval, int ntab, const double* x,
+hipError_t launch_dict_jacobi_prolong(int64_t n, const DictRef& D, const double* x,
                                       const double* f, double* out, double omega, int64_t n_h,
                                       double* uh, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  if (!dict_args_ok(n_h, words, wmax, ntab) || n > n_h || !uh ||
+  if (!dict_args_ok(n_h, D.words, D.wmax, D.ntab) || n > n_h || !uh ||
       (reinterpret_cast<uintptr_t>(uh) & 15) != 0)
     return hipErrorInvalidValue;
-  const bool two = g_dict_rows_per_lane == 2 && n >= 4096 && aligned16(f, out, codes);
+  const bool two = dict_two_rows(n, D, f, out);
   const int64_t stride = 256 * (two ? 2 : 1) - 2;
   const unsigned tiles = (unsigned)((n + stride - 1) / stride);
-  return dict_dispatch(words, wmax, nt != 0, two, [&](auto W, auto U, auto NTF, auto RR) {
+  return dict_dispatch(D.words, D.wmax, D.nt != 0, two, [&](auto W, auto U, auto NTF, auto RR) {
     hipLaunchKernelGGL((dict_jacobi_prolong_kernel<decltype(W)::value, decltype(U)::value,
                                                    decltype(NTF)::value, decltype(RR)::value>),
-                       dim3(tiles), dim3(256), 0, st, (int)n, codes, doff, dval, ntab, x, f, out,
-                       omega, (int)n_h, uh, g_xcd_map);
+                       dim3(tiles), dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff,
+                       D.dval, D.ntab, x, f, out, omega, (int)n_h, uh, g_xcd_map);
   });
 }
 void set_xcd_mapping(int on) { g_xcd_map = on ? 1 : 0; }
 void set_dict_rows_per_lane(int r) { g_dict_rows_per_lane = r == 1 ? 1 : 2; }
-hipError_t launch_dict(int mode, int64_t n, int words, int wmax, int nt, const uint64_t* codes,
-                       const int32_t* doff, const double* dval, int ntab, const double* x,
-                       const double* f, double* out, double omega, int64_t diag_shift,
-                       hipStream_t st) {
+template <int MODE>
+static hipError_t launch_dict_mode(int64_t n, const DictRef& D, const double* x, const double* f,
+                                   double* out, double omega, int64_t dshift, hipStream_t st) {
+  const bool two = dict_two_rows(n, D, f, out);
+  const unsigned tiles = (unsigned)((n + 256 * (two ? 2 : 1) - 1) / (256 * (two ? 2 : 1)));
+  return dict_dispatch(D.words, D.wmax, D.nt != 0, two, [&](auto W, auto U, auto NTF, auto RR) {
+    hipLaunchKernelGGL((dict_kernel<MODE, decltype(W)::value, decltype(U)::value,
+                                    decltype(NTF)::value, decltype(RR)::value>),
+                       dim3(tiles), dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff,
+                       D.dval, D.ntab, x, f, out, omega, (int)dshift, g_xcd_map);
+  });
+}
+hipError_t launch_dict(int mode, int64_t n, const DictRef& D, const double* x, const double* f,
+                       double* out, double omega, int64_t diag_shift, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  if (n >= ((int64_t)1 << 31) - 256 || diag_shift >= ((int64_t)1 << 30) || ntab > 255 ||
-      (words != 1 && words != 2) || wmax > 8 * words)
+  if (!dict_args_ok(n, D.words, D.wmax, D.ntab) || diag_shift >= ((int64_t)1 << 28))
     return hipErrorInvalidValue;
   switch (mode) {
-    case CSR_RESID: return launch_dict_mode<CSR_RESID>(n, words, wmax, nt != 0, codes, doff, dval, ntab, x, f, out, omega, diag_shift, st);
-    case CSR_JACOBI: return launch_dict_mode<CSR_JACOBI>(n, words, wmax, nt != 0, codes, doff, dval, ntab, x, f, out, omega, diag_shift, st);
-    case CSR_SPMV: return launch_dict_mode<CSR_SPMV>(n, words, wmax, nt != 0, codes, doff, dval, ntab, x, f, out, omega, diag_shift, st);
-    case CSR_RSSQ: return launch_dict_mode<CSR_RSSQ>(n, words, wmax, nt != 0, codes, doff, dval, ntab, x, f, out, omega, diag_shift, st);
+    case CSR_RESID: return launch_dict_mode<CSR_RESID>(n, D, x, f, out, omega, diag_shift, st);
+    case CSR_JACOBI: return launch_dict_mode<CSR_JACOBI>(n, D, x, f, out, omega, diag_shift, st);
+    case CSR_SPMV: return launch_dict_mode<CSR_SPMV>(n, D, x, f, out, omega, diag_shift, st);
+    case CSR_RSSQ: return launch_dict_mode<CSR_RSSQ>(n, D, x, f, out, omega, diag_shift, st);
   }
   return hipErrorInvalidValue;
 }

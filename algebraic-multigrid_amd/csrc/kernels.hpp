@@ -31,8 +31,18 @@ hipError_t launch_sell(int mode, int64_t n, int idx16, const int64_t* soff,
 // prolongation + add (multigrid.hpp:294-296) fused into the first post-smoothing
 // sweep; u itself is not modified.
 // K-Dict: dictionary-coded rows (host_setup.hpp: DictMat); modes as launch_sell.
+struct DictRef {  // device pointers of one dictionary-coded matrix
+  int words = 1, wmax = 0, nt = 0, ntab = 0;
+  const uint64_t* codes = nullptr;   // n * words code words (unused when rtype is set)
+  const uint8_t* rtype = nullptr;    // optional: one byte per row into rwords
+  const uint64_t* rwords = nullptr;  // 256 * words, entry 255 = all 0xFF
+  const int32_t* doff = nullptr;     // pair table: column offset from the diagonal column
+  const double* dval = nullptr;      //             value
+};
 void set_xcd_mapping(int on);  // contiguous run of tiles per XCD (default on)
 void set_dict_rows_per_lane(int r);  // 1 or 2 (default), tuning / test switch
+hipError_t launch_dict(int mode, int64_t n, const DictRef& D, const double* x, const double* f,
+                       double* out, double omega, int64_t diag_shift, hipStream_t st);
 // one colour of the multicolour GS sweep on a dictionary-coded colour-permuted copy
 hipError_t launch_dict_gs_color(int64_t p0, int64_t count, int words, int wmax,
                                 const uint64_t* codes, const int32_t* rowid, const int32_t* doff,
@@ -41,16 +51,12 @@ hipError_t launch_dict_gs_color(int64_t p0, int64_t count, int words, int wmax,
 // fused forms for the true-Jacobi V-cycle on linear-interpolation levels (kernels.hip):
 // r = f - A x (written), f_H = R r, and either uH1 = first Jacobi sweep of the coarse level
 // from zero (needs diagH) or, with uH1 == nullptr, uH0 = 0
-hipError_t launch_dict_resid_restrict(int64_t n, int words, int wmax, int nt,
-                                      const uint64_t* codes, const int32_t* doff,
-                                      const double* dval, int ntab, const double* x,
+hipError_t launch_dict_resid_restrict(int64_t n, const DictRef& D, const double* x,
                                       const double* f, double* r_out, int64_t nH, double* fH,
                                       const double* diagH, double* uH1, double* uH0,
                                       double omega, hipStream_t st);
 // out = Jacobi sweep of x on this (coarse) level, then uh += P out on the finer level
-hipError_t launch_dict_jacobi_prolong(int64_t n, int words, int wmax, int nt,
-                                      const uint64_t* codes, const int32_t* doff,
-                                      const double* dval, int ntab, const double* x,
+hipError_t launch_dict_jacobi_prolong(int64_t n, const DictRef& D, const double* x,
                                       const double* f, double* out, double omega, int64_t n_h,
                                       double* uh, hipStream_t st);
 hipError_t launch_dict(int mode, int64_t n, int words, int wmax, int nt, const uint64_t* codes,

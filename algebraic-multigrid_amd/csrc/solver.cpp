@@ -185,8 +185,21 @@ struct DevMat {
   bool dict = false;          // K-Dict (dictionary-coded rows)
   int dict_words = 0, dict_wmax = 0, dict_ntab = 0, dict_nt = 0;
   int64_t dict_shift = 0;
-  DevMem dcodes, doff, dval;
+  bool dict_typed = false;    // second level: one byte per row into a table of code words
+  DevMem dcodes, doff, dval, drtype, drwords;
+  DictRef dict_ref() const {
+    DictRef D;
+    D.words = dict_words; D.wmax = dict_wmax; D.nt = dict_nt; D.ntab = dict_ntab;
+    D.codes = dcodes.as<uint64_t>();
+    D.rtype = dict_typed ? drtype.as<uint8_t>() : nullptr;
+    D.rwords = dict_typed ? drwords.as<uint64_t>() : nullptr;
+    D.doff = doff.as<int32_t>();
+    D.dval = dval.as<double>();
+    return D;
+  }
 };
+
+int g_row_types = 1;  // use the second-level (row type) coding when a matrix allows it
 
 int g_index16 = 1;  // use 16-bit relative column indices when a matrix allows it
 int g_nontemporal = 1;  // stream large matrices with non-temporal loads
@@ -251,8 +264,14 @@ hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift
       D->dict_shift = diag_shift;
       // one sweep streams codes + f + out and gathers x: non-temporal stream when
       // that is well beyond the 256 MiB Infinity Cache
-      const double stream_bytes = (double)M.n_outer * (8.0 * T.words + 24.0);
+      D->dict_typed = g_row_types != 0 && !T.rtype.empty();
+      const double stream_bytes =
+          (double)M.n_outer * ((D->dict_typed ? 1.0 : 8.0 * T.words) + 24.0);
       D->dict_nt = (g_nontemporal && stream_bytes > 192.0e6) ? 1 : 0;
+      if (D->dict_typed) {
+        if ((e = upload(D->drtype, T.rtype.data(), T.rtype.size())) != hipSuccess) return e;
+        if ((e = upload(D->drwords, T.rwords.data(), T.rwords.size())) != hipSuccess) return e;
+      }
       if ((e = upload(D->dcodes, T.codes.data(), T.codes.size())) != hipSuccess) return e;
       if ((e = upload(D->doff, T.doff.data(), T.doff.size())) != hipSuccess) return e;
       return upload(D->dval, T.dval.data(), T.dval.size());
@@ -308,9 +327,7 @@ hipError_t launch_mat(int mode, const DevMat& A, const double* x, const double* 
                       double omega, hipStream_t st, int64_t diag_shift = 0) {
   if (A.dict) {
     if (diag_shift != A.dict_shift) return hipErrorInvalidValue;  // offsets are baked in
-    return launch_dict(mode, A.n_rows, A.dict_words, A.dict_wmax, A.dict_nt,
-                       A.dcodes.as<uint64_t>(), A.doff.as<int32_t>(), A.dval.as<double>(),
-                       A.dict_ntab, x, f, out, omega, diag_shift, st);
+    return launch_dict(mode, A.n_rows, A.dict_ref(), x, f, out, omega, diag_shift, st);
   }
   if (A.sell)
     return launch_sell(mode, A.n_rows, A.idx16, A.soff.as<int64_t>(), A.scol.p,
@@ -526,11 +543,8 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
       for (; it < iters; ++it) {
         if (prolong_into >= 0 && it == iters - 1) {
           Level& F = s->lv[prolong_into];
-          HIP_TRY(launch_dict_jacobi_prolong(A.n_rows, A.dict_words, A.dict_wmax, A.dict_nt,
-                                             A.dcodes.as<uint64_t>(), A.doff.as<int32_t>(),
-                                             A.dval.as<double>(), A.dict_ntab, a,
-                                             L.f.as<double>(), b, s->opt.omega, F.n,
-                                             F.u.as<double>(), st));
+          HIP_TRY(launch_dict_jacobi_prolong(A.n_rows, A.dict_ref(), a, L.f.as<double>(), b,
+                                             s->opt.omega, F.n, F.u.as<double>(), st));
         } else {
           HIP_TRY(launch_mat(CSR_JACOBI, A, a, L.f.as<double>(), b, s->opt.omega, st));
         }
@@ -592,9 +606,7 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
       Level& L = s->lv[l];
       Level& C = s->lv[l + 1];
       const DevMat& A = L.A_rows;
-      HIP_TRY(launch_dict_resid_restrict(A.n_rows, A.dict_words, A.dict_wmax, A.dict_nt,
-                                         A.dcodes.as<uint64_t>(), A.doff.as<int32_t>(),
-                                         A.dval.as<double>(), A.dict_ntab, L.u.as<double>(),
+      HIP_TRY(launch_dict_resid_restrict(A.n_rows, A.dict_ref(), L.u.as<double>(),
                                          L.f.as<double>(), L.r.as<double>(), C.n,
                                          C.f.as<double>(),
                                          zero_known ? C.diag.as<double>() : nullptr,
@@ -990,6 +1002,7 @@ void amg_hip_default_options(amg_hip_options* o) {
 void amg_hip_set_index16(int32_t on) { g_index16 = on ? 1 : 0; }
 void amg_hip_set_nontemporal(int32_t on) { g_nontemporal = on ? 1 : 0; }
 void amg_hip_set_xcd_mapping(int32_t on) { set_xcd_mapping(on); }
+void amg_hip_set_row_types(int32_t on) { g_row_types = on ? 1 : 0; }
 void amg_hip_set_dict_rows(int32_t rows_per_lane) { set_dict_rows_per_lane(rows_per_lane); }
 
 void amg_hip_set_default_layout(int32_t layout) {
@@ -1237,7 +1250,8 @@ static void layout_of(const DevMat& A, int32_t* layout, int64_t* matrix_stream_b
   int64_t bytes;
   if (A.dict) {
     lay = AMG_HIP_LAYOUT_DICT;
-    bytes = A.n_rows * 8 * A.dict_words + (int64_t)A.dict_ntab * 12;
+    bytes = (A.dict_typed ? A.n_rows + 256 * 8 * A.dict_words : A.n_rows * 8 * A.dict_words) +
+            (int64_t)A.dict_ntab * 12;
   } else if (A.sell) {
     lay = AMG_HIP_LAYOUT_SELL;
     bytes = A.slots * ((A.idx16 & 1) ? 10 : 12) + (A.n_rows + 63) / 64 * 8;

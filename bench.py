@@ -72,6 +72,7 @@ def run_single(args):
     if args.no_nt:
         amg.lib().amg_hip_set_nontemporal(0)
     amg.set_dict_rows(args.dict_rows)
+    amg.set_row_types(not args.no_row_types)
     amg.set_xcd_mapping(not args.no_xcd_map)
     amg.set_default_layout({"auto": amg.LAYOUT_AUTO, "csr": amg.LAYOUT_CSR, "sell": amg.LAYOUT_SELL,
                             "dict": amg.LAYOUT_DICT}[args.layout])
@@ -218,6 +219,7 @@ def main():
                          "matrix qualifies, else SELL-64)")
     ap.add_argument("--no-nt", action="store_true", help="disable the non-temporal matrix stream")
     ap.add_argument("--no-xcd-map", action="store_true", help="K-Dict: plain blockIdx -> tile mapping")
+    ap.add_argument("--no-row-types", action="store_true", help="K-Dict: first-level coding only")
     ap.add_argument("--dict-rows", type=int, default=2, choices=[1, 2], help="K-Dict rows per lane")
     ap.add_argument("--fast-coarse", action="store_true",
                     help="partitioned (parallel) coarse solve; then fewer levels pay off (--levels 13)")

@@ -63,7 +63,9 @@ typedef enum {
   AMG_HIP_LAYOUT_DICT = 3  /* dictionary-coded rows (K-Dict): one byte per entry
                               indexing a table of the matrix's distinct
                               (column offset, value) pairs; needs <= 255 pairs
-                              and rows of <= 16 entries, else falls back to SELL */
+                              and rows of <= 16 entries, else falls back to SELL.
+                              With <= 255 distinct rows the whole row is one byte
+                              (amg_hip_set_row_types)                             */
 } amg_hip_layout;
 
 /* Options of amg_hip_create.  Zero-initialise, then amg_hip_default_options. */
@@ -127,6 +129,11 @@ void amg_hip_set_nontemporal(int32_t on);
 /* K-Dict: give every XCD one contiguous run of row tiles, so that the +-bandwidth
  * re-reads of x hit the L2 that fetched them (default on).  Tuning switch.       */
 void amg_hip_set_xcd_mapping(int32_t on);
+/* K-Dict second level: when a dictionary-coded matrix has at most 255 distinct rows, store
+ * one byte per row into a table of code words instead of the code words themselves
+ * (process-wide, default on; bit-identical results).  Applies to matrices uploaded
+ * after the call.                                                                */
+void amg_hip_set_row_types(int32_t on);
 /* K-Dict rows per lane: 2 (default; 16-byte lane accesses) or 1.  Process-wide;
  * bit-identical results, a tuning / test switch.                                */
 void amg_hip_set_dict_rows(int32_t rows_per_lane);

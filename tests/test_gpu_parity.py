@@ -18,21 +18,24 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.fixture(autouse=True, params=["csr", "sell", "sell_idx32", "dict", "dict_r1"])
+@pytest.fixture(autouse=True, params=["csr", "sell", "sell_idx32", "dict", "dict_r1", "dict_words"])
 def layout(request, amg):
     """Every test runs once per device layout / kernel variant: level matrices as plain
     CSR (LDS-staged K-CSR kernel), as SELL-64 panels with 16-bit relative column
     indices, as SELL-64 with plain int32 columns, and dictionary-coded (K-Dict, the
-    default wherever a matrix qualifies, SELL otherwise) with two rows per lane and
-    with one.  Results must be bit-identical in all of them."""
+    default wherever a matrix qualifies, SELL otherwise) with two rows per lane, with
+    one, and without the second-level row types.  Results must be bit-identical in all
+    of them."""
     amg.set_default_layout(amg.LAYOUT_CSR if request.param == "csr" else
                            amg.LAYOUT_DICT if request.param.startswith("dict") else amg.LAYOUT_SELL)
     amg.set_dict_rows(1 if request.param == "dict_r1" else 2)
+    amg.set_row_types(request.param != "dict_words")   # dict_words: first-level coding only
     amg.set_index16(request.param != "sell_idx32")
     yield request.param
     amg.set_default_layout(amg.LAYOUT_AUTO)
     amg.set_index16(True)
     amg.set_dict_rows(2)
+    amg.set_row_types(True)
 
 
 def csc(A):

@@ -43,21 +43,25 @@ def level_of(rows):
     return None
 
 
+ROW_TYPES = True   # second-level coding: one byte per row instead of 8 * words
+
+
 def format_bytes(kind, l, words):
     """bytes the layout itself must move per launch"""
     n = LEVEL_ROWS[l]
-    if kind in ("sweep", "resid"):          # codes + f + x + out
-        return n * (8 * words + 24)
+    mat = 1 if ROW_TYPES else 8 * words
+    if kind in ("sweep", "resid"):          # row types / codes + f + x + out
+        return n * (mat + 24)
     if kind == "resid_restrict":            # + f_H, first coarse sweep out, coarse diagonal in
-        return n * (8 * words + 24) + LEVEL_ROWS[l + 1] * 24
+        return n * (mat + 24) + LEVEL_ROWS[l + 1] * 24
     if kind == "jacobi_prolong":            # + read-modify-write of the finer u
-        return n * (8 * words + 24) + LEVEL_ROWS[l - 1] * 16
+        return n * (mat + 24) + LEVEL_ROWS[l - 1] * 16
     return None
 
 
 def main():
     f, w, tag = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
-    note = sys.argv[4] if len(sys.argv) > 4 else "K-Dict (dictionary-coded rows)"
+    note = sys.argv[4] if len(sys.argv) > 4 else "K-Dict (dictionary-coded rows, one byte per row)"
     # 4096^2 hierarchy: rows and nnz of levels 0, 1, 2 (CSR formula 12 nnz + 28 n)
     lv = {16777216: 83869696, 8388607: 75485173, 4194303: 37742581}
     lv_pad = {16777216: 16777216, 8388608: 8388607, 4194304: 4194303}
