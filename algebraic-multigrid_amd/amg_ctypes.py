@@ -166,11 +166,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("AMG_HIP_LIBRARY", LIB_PATH)   # another build of the same ABI
+        if not os.path.exists(path):
             raise ImportError(
-                f"{LIB_PATH} not found: build it with `make -C {_HERE}` "
+                f"{path} not found: build it with `make -C {_HERE}` "
                 "(or __graft_entry__.build()); there is no fallback implementation")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype = res

@@ -112,7 +112,7 @@ def run_single(args):
     # what the format has to move per sweep: matrix stream + f + x + out (8 B each per row)
     format_bytes = mat_bytes + 24 * sizes[0]
     kernel = {"dict": ("dict_kernel<CSR_JACOBI, 1 code word, 5 entries, nt, 2 rows/lane> (level-0 Jacobi sweep, "
-                       "dictionary-coded rows)", "r01e_pmc_traffic", "dict_kernel<1, 1, 5, true, 2>@L0"),
+                       "dictionary-coded rows, one byte per row)", "r01f_pmc_traffic", "dict_kernel<1, 1, 5, true, 2>@L0"),
               "sell": ("sell_kernel<CSR_JACOBI, idx16, nt> (level-0 Jacobi sweep, SELL-64 panels)",
                        "r01c_pmc_traffic", "sell_kernel<1, true, true>@16777216"),
               "csr": ("csr_stage_kernel<CSR_JACOBI> (level-0 Jacobi sweep, LDS-staged CSR)", None, None)}[lay_name]
@@ -164,7 +164,7 @@ def run_single(args):
             "hbm_frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "note": ("achieved/frac use the CSR-formula bytes of SURVEY 8(d) (12 nnz + 28 n per sweep), i.e. "
                      "the CSR-equivalent rate; the dictionary-coded layout moves format_bytes_per_launch "
-                     "(8 B of codes + f + x + out per row), so frac can exceed 1 -- hbm_*_measured is the "
+                     "(1 B of row type + f + x + out per row), so frac can exceed 1 -- hbm_*_measured is the "
                      "PMC traffic over the same launch time against the 8 TB/s peak") if lay_name == "dict" else None,
             "avg_launch_ms": avg_ms,
             "min_launch_ms": min_ms,
