@@ -37,7 +37,7 @@ class Options(C.Structure):
                 ("host_only", C.c_int32), ("keep_structural_zeros", C.c_int32),
                 ("no_fusion", C.c_int32), ("fuse_prolong", C.c_int32),
                 ("fast_coarse_solve", C.c_int32), ("host_galerkin", C.c_int32),
-                ("reserved", C.c_int32 * 1),
+                ("keep_residual", C.c_int32),
                 ("stream", C.c_void_p)]
 
 
@@ -255,7 +255,7 @@ class Multigrid:
                  n_iters=100, device=-1, use_graph=True, stencil_transfers=True,
                  transfers=None, layout=None, host_only=False, keep_structural_zeros=False,
                  no_fusion=False, fuse_prolong=False, stream=None, fast_coarse_solve=False,
-                 host_galerkin=False):
+                 host_galerkin=False, keep_residual=False):
         # multigrid.hpp:165-178 (same checks, same order)
         if compute_error_every_n_iters > n_iters:
             raise ValueError("`compute_error_every_n_iters` must be leq to `n_iters`, got "
@@ -280,6 +280,7 @@ class Multigrid:
         o.fuse_prolong = int(fuse_prolong)
         o.fast_coarse_solve = int(fast_coarse_solve)
         o.host_galerkin = int(host_galerkin)
+        o.keep_residual = int(keep_residual)
         if stream:
             o.stream = C.c_void_p(stream)
         h = C.c_void_p()

@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void dict_resid_restrict_kernel(
   if (rtype) dict_expand<WORDS, R>(s, wtab);
   double res[R];
   dict_rows<CSR_RESID, WORDS, UN, R>(s, row0, tab, x, omega, 0, res);
-  dict_store<WORDS, NT, R>(s, row0, res, r_out);
+  if (r_out) dict_store<WORDS, NT, R>(s, row0, res, r_out);  // nullptr: r is dead after this kernel
 #pragma unroll
   for (int r = 0; r < R; ++r) rs[threadIdx.x * R + r] = s.live[r] ? res[r] : 0.0;
   __syncthreads();
@@ -858,7 +858,7 @@ hipError_t launch_dict_resid_restrict(int64_t n, const DictRef& D, const double*
   if (n <= 0) return hipSuccess;
   if (!dict_args_ok(n, D.words, D.wmax, D.ntab) || nH > n || !fH || (uH1 ? !diagH : !uH0))
     return hipErrorInvalidValue;
-  const bool two = dict_two_rows(n, D, f, r_out);
+  const bool two = dict_two_rows(n, D, f, r_out);  // r_out may be nullptr (not stored)
   const int64_t stride = 256 * (two ? 2 : 1) - 2;
   const unsigned tiles = (unsigned)((n + stride - 1) / stride);
   return dict_dispatch(D.words, D.wmax, D.nt != 0, two, [&](auto W, auto U, auto NTF, auto RR) {

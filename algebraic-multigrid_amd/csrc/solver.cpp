@@ -607,7 +607,8 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
       Level& C = s->lv[l + 1];
       const DevMat& A = L.A_rows;
       HIP_TRY(launch_dict_resid_restrict(A.n_rows, A.dict_ref(), L.u.as<double>(),
-                                         L.f.as<double>(), L.r.as<double>(), C.n,
+                                         L.f.as<double>(),
+                                         s->opt.keep_residual ? L.r.as<double>() : nullptr, C.n,
                                          C.f.as<double>(),
                                          zero_known ? C.diag.as<double>() : nullptr,
                                          zero_known ? C.tmp.as<double>() : nullptr,
@@ -1228,6 +1229,9 @@ amg_hip_status amg_hip_get_vec(amg_hip_solver* s, int32_t level, int32_t which, 
   DevMem* m = pick_vec(s, level, which);
   if (!m || !out) return fail(AMG_HIP_EINVAL, "bad level / vector selector");
   if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "host_only solver has no vectors");
+  if (which == 2 && !s->opt.keep_residual && fuses_resid_restrict(s, level))
+    return fail(AMG_HIP_EINVAL, "the residual of this level is not kept (create the solver with "
+                                "opt.keep_residual = 1)");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipMemcpy(out, m->p, sizeof(double) * s->lv[level].n, hipMemcpyDeviceToHost));

@@ -102,7 +102,12 @@ typedef struct {
   int32_t host_galerkin;   /* 1: build the Galerkin products R (A P) on the host instead of
                               on the device (same entries, same bits; the device path
                               is taken for LinearInterpolator operators only)        */
-  int32_t reserved[1];
+  int32_t keep_residual;   /* 1: keep the level residuals r = f - A u readable through
+                              amg_hip_get_vec(level, 2).  The reference holds them as
+                              private workspace without a getter (multigrid.hpp:107), so
+                              by default (0) the fused residual+restriction kernel does
+                              not store r on the levels where it runs, and reading it
+                              there returns AMG_HIP_EINVAL.                            */
   void* stream;            /* hipStream_t to run on; NULL (default) = the solver creates
                               and owns a non-blocking stream.  A caller that already
                               orders its device work on a stream (torch's current

@@ -268,7 +268,7 @@ def test_vcycle_config1_bit_exact_and_golden(amg, oracle):
     n, L = 128, 3
     A, b = oracle.laplacian(n), oracle.rhs(n)
     ref = oracle.Multigrid(A, b, L)
-    mg = amg.Multigrid(*csc(A), b, L)
+    mg = amg.Multigrid(*csc(A), b, L, keep_residual=True)
     gold = json.load(open(os.path.join(GOLD, "kat_config1.json")))
     for c in range(12):
         ref.vcycle()
@@ -478,7 +478,8 @@ def test_jacobi_fusions_and_zero_pruning_are_bit_neutral(amg, oracle):
     ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
     variants = [dict(), dict(no_fusion=True), dict(keep_structural_zeros=True), dict(fuse_prolong=True),
                 dict(no_fusion=True, keep_structural_zeros=True), dict(stencil_transfers=False)]
-    mgs = [amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6, **kw)
+    mgs = [amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6,
+                         keep_residual=True, **kw)
            for kw in variants]
     for c in range(4):
         ref.vcycle()
@@ -501,6 +502,28 @@ def test_jacobi_fusions_and_zero_pruning_are_bit_neutral(amg, oracle):
     mg.close()
 
 
+def test_residual_is_private_workspace_by_default(amg, oracle):
+    """multigrid.hpp:107: level_to_residual has no getter.  Without keep_residual the fused
+    residual+restriction kernel does not store r; u and f are unaffected, reading r on a
+    fused level is an error, the coarsest level (plain residual kernel) still has it."""
+    n, L = 80, 4
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
+    mg = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
+    for _ in range(3):
+        ref.vcycle()
+        mg.vcycle()
+    for l in range(L):
+        assert np.array_equal(mg.get_soln(l), ref.get_vec(l, "u"))
+        assert np.array_equal(mg.get_rhs(l), ref.get_vec(l, "f"))
+    assert np.array_equal(mg.get_residual(L - 1), ref.get_vec(L - 1, "r"))
+    lay, _ = mg.level_layout(0)
+    if lay == amg.LAYOUT_DICT:        # the fusion needs the dictionary-coded layout
+        with pytest.raises(amg.AmgHipError):
+            mg.get_residual(0)
+    mg.close()
+
+
 def test_fused_level_kernels_at_tile_boundaries(amg, oracle):
     """The fused residual+restriction+first-coarse-sweep and sweep+prolongation kernels
     work on overlapping tiles of 256 or 512 rows (stride 254 / 510, one or two rows per
@@ -520,7 +543,8 @@ def test_fused_level_kernels_at_tile_boundaries(amg, oracle):
         b = np.cos(0.37 * np.arange(n)) + 1.5
         L = 3
         ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
-        mg = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
+        mg = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6,
+                           keep_residual=True)
         for c in range(2):
             ref.vcycle()
             mg.vcycle()
