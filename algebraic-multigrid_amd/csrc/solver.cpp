@@ -598,6 +598,10 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
   const bool zero_known = jacobi_fuses_zero(s);  // coarse pre-smoothing starts from u == 0
   bool first_sweep_done = false;  // by the fused residual+restrict kernel of level l-1
   for (int l = 0; l < nl; ++l) {
+    // On the coarsest level the reference smooths and forms the residual, then overwrites
+    // u with the direct solve of the level's rhs (multigrid.hpp:268-274, :287-288): unless
+    // the residual is to be kept, neither has an observable effect.
+    if (l == nl - 1 && nl > 1 && !s->opt.keep_residual) break;
     amg_hip_status r =
         enqueue_smooth(s, l, first_sweep_done ? 3 : (l >= 1 && zero_known) ? 1 : 0);  // :268
     if (r != AMG_HIP_OK) return r;
@@ -1229,7 +1233,8 @@ amg_hip_status amg_hip_get_vec(amg_hip_solver* s, int32_t level, int32_t which, 
   DevMem* m = pick_vec(s, level, which);
   if (!m || !out) return fail(AMG_HIP_EINVAL, "bad level / vector selector");
   if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "host_only solver has no vectors");
-  if (which == 2 && !s->opt.keep_residual && fuses_resid_restrict(s, level))
+  if (which == 2 && !s->opt.keep_residual &&
+      (fuses_resid_restrict(s, level) || (level == (int32_t)s->lv.size() - 1 && level > 0)))
     return fail(AMG_HIP_EINVAL, "the residual of this level is not kept (create the solver with "
                                 "opt.keep_residual = 1)");
   HIP_TRY(hipSetDevice(s->device));

@@ -504,8 +504,8 @@ def test_jacobi_fusions_and_zero_pruning_are_bit_neutral(amg, oracle):
 
 def test_residual_is_private_workspace_by_default(amg, oracle):
     """multigrid.hpp:107: level_to_residual has no getter.  Without keep_residual the fused
-    residual+restriction kernel does not store r; u and f are unaffected, reading r on a
-    fused level is an error, the coarsest level (plain residual kernel) still has it."""
+    residual+restriction kernel does not store r and the coarsest level skips its (dead)
+    smoothing and residual; u and f are unaffected, reading r there is an error."""
     n, L = 80, 4
     A, b = oracle.laplacian(n), oracle.rhs(n)
     ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
@@ -516,7 +516,8 @@ def test_residual_is_private_workspace_by_default(amg, oracle):
     for l in range(L):
         assert np.array_equal(mg.get_soln(l), ref.get_vec(l, "u"))
         assert np.array_equal(mg.get_rhs(l), ref.get_vec(l, "f"))
-    assert np.array_equal(mg.get_residual(L - 1), ref.get_vec(L - 1, "r"))
+    with pytest.raises(amg.AmgHipError):   # coarsest: smoothing + residual are dead work there
+        mg.get_residual(L - 1)
     lay, _ = mg.level_layout(0)
     if lay == amg.LAYOUT_DICT:        # the fusion needs the dictionary-coded layout
         with pytest.raises(amg.AmgHipError):
