@@ -52,8 +52,8 @@ def format_bytes(kind, l, words):
     mat = 1 if ROW_TYPES else 8 * words
     if kind in ("sweep", "resid"):          # row types / codes + f + x + out
         return n * (mat + 24)
-    if kind == "resid_restrict":            # + f_H, first coarse sweep out, coarse diagonal in
-        return n * (mat + 24) + LEVEL_ROWS[l + 1] * 24
+    if kind == "resid_restrict":            # r is not stored (opt.keep_residual = 0);
+        return n * (mat + 16) + LEVEL_ROWS[l + 1] * 24   # + f_H, first coarse sweep out, coarse diagonal in
     if kind == "jacobi_prolong":            # + read-modify-write of the finer u
         return n * (mat + 24) + LEVEL_ROWS[l - 1] * 16
     return None
