@@ -133,6 +133,8 @@ _SIGS = {
     "amg_hip_set_dict_rows": (None, [C.c_int32]),
     "amg_hip_set_xcd_mapping": (None, [C.c_int32]),
     "amg_hip_set_row_types": (None, [C.c_int32]),
+    "amg_hip_dict_probe": (C.c_int, [C.c_int64, C.c_int64, _i32p, _i32p, _f64p, C.c_int64,
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "amg_hip_devmat_destroy": (None, [C.c_void_p]),
     "amg_hip_devmat_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "amg_hip_devmat_apply": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -215,6 +217,19 @@ def set_index16(on):
 
 def set_dict_rows(rows_per_lane):
     lib().amg_hip_set_dict_rows(int(rows_per_lane))
+
+
+def dict_probe(rowptr, col, val, ncols, diag_shift=0):
+    """Host-only: (n_pairs, n_row_types, words) of the dictionary coding of a CSR block, or
+    None when the block does not qualify.  Raises when the coding does not round-trip."""
+    rowptr, col, val = _a32(rowptr), _a32(col), _a64(val)
+    a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    st = lib().amg_hip_dict_probe(rowptr.size - 1, ncols, _p32(rowptr), _p32(col), _p64(val),
+                                  diag_shift, C.byref(a), C.byref(b), C.byref(c))
+    if st == EUNSUPPORTED:
+        return None
+    _chk(st)
+    return a.value, b.value, c.value
 
 
 def set_row_types(on):

@@ -1792,6 +1792,50 @@ static amg_hip_status dev_csr(int mode, int64_t nrows, int64_t nnz, int32_t max_
   return AMG_HIP_OK;
 }
 
+amg_hip_status amg_hip_dict_probe(int64_t nrows, int64_t ncols, const int32_t* rowptr,
+                                  const int32_t* col, const double* val, int64_t diag_shift,
+                                  int32_t* n_pairs, int32_t* n_row_types, int32_t* words) {
+  if (nrows < 0 || ncols < 0 || !rowptr || (rowptr[nrows] > 0 && (!col || !val)))
+    return fail(AMG_HIP_EINVAL, "bad argument");
+  Sparse M = from_raw(nrows, ncols, rowptr, col, val);
+  std::string v = validate(M, "matrix");
+  if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
+  DictMat T;
+  if (!to_dict(M, diag_shift, &T))
+    return fail(AMG_HIP_EUNSUPPORTED, "the matrix does not qualify for the dictionary coding");
+  // decode: row type -> code words -> (offset, value) pairs, compare with the input
+  const bool typed = !T.rtype.empty();
+  for (int64_t r = 0; r < nrows; ++r) {
+    uint64_t w[2] = {~(uint64_t)0, ~(uint64_t)0};
+    for (int k = 0; k < T.words; ++k)
+      w[k] = typed ? T.rwords[(size_t)T.rtype[r] * T.words + k] : T.codes[(size_t)r * T.words + k];
+    if (typed)
+      for (int k = 0; k < T.words; ++k)
+        if (w[k] != T.codes[(size_t)r * T.words + k])
+          return fail(AMG_HIP_EHIP, "row type table does not reproduce the code words");
+    int j = 0;
+    for (int32_t q = rowptr[r]; q < rowptr[r + 1]; ++q, ++j) {
+      const int code = (int)((w[j >> 3] >> (8 * (j & 7))) & 0xFF);
+      if (code == 0xFF || code >= (int)T.doff.size() ||
+          (int64_t)T.doff[code] + r + diag_shift != (int64_t)col[q] ||
+          std::memcmp(&T.dval[code], &val[q], sizeof(double)) != 0)
+        return fail(AMG_HIP_EHIP, "dictionary coding does not round-trip");
+    }
+    for (; j < 8 * T.words; ++j)
+      if (((w[j >> 3] >> (8 * (j & 7))) & 0xFF) != 0xFF)
+        return fail(AMG_HIP_EHIP, "dictionary coding has entries past the end of a row");
+  }
+  if (n_pairs) *n_pairs = (int32_t)T.doff.size();
+  if (n_row_types) {
+    int32_t nt = 0;
+    if (typed)
+      for (uint8_t t : T.rtype) nt = std::max<int32_t>(nt, (int32_t)t + 1);
+    *n_row_types = nt;
+  }
+  if (words) *words = T.words;
+  return AMG_HIP_OK;
+}
+
 amg_hip_status amg_hip_csr_shape(int64_t nrows, const int32_t* rowptr_host,
                                  int32_t* max_block_nnz, int32_t* max_row_nnz) {
   if (nrows < 0 || !rowptr_host) return fail(AMG_HIP_EINVAL, "bad argument");

@@ -329,6 +329,16 @@ amg_hip_status amg_hip_rhs(int32_t dim, int64_t n, double* b);
  * CSR here = row-major view (rowptr/col/val); for a symmetric A the CSC arrays
  * are the CSR arrays.  Column indices address `u` directly, so a rank passes a
  * halo-extended local vector and locally renumbered columns.                  */
+/* Host-only probe of the dictionary coding (no device needed): encodes the CSR block
+ * the way amg_hip_devmat_create / the level upload would (exact zeros are NOT dropped
+ * here), decodes it again and compares with the input.  AMG_HIP_OK: the block qualifies
+ * and the round trip is exact; n_pairs = distinct (column offset, value) pairs,
+ * n_row_types = distinct rows as whole code words (0 when more than 255, i.e. first
+ * level only), words = 64-bit code words per row.  AMG_HIP_EUNSUPPORTED: it does not
+ * qualify (more than 255 pairs, a row longer than 16 entries, ...).              */
+amg_hip_status amg_hip_dict_probe(int64_t nrows, int64_t ncols, const int32_t* rowptr,
+                                  const int32_t* col, const double* val, int64_t diag_shift,
+                                  int32_t* n_pairs, int32_t* n_row_types, int32_t* words);
 /* Launch parameters of the CSR kernels, computed from a HOST copy of rowptr:
  * max entries in any block of 256 consecutive rows, and the longest row.     */
 amg_hip_status amg_hip_csr_shape(int64_t nrows, const int32_t* rowptr_host,
