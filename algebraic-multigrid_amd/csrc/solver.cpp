@@ -268,11 +268,12 @@ hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift
       const double stream_bytes =
           (double)M.n_outer * ((D->dict_typed ? 1.0 : 8.0 * T.words) + 24.0);
       D->dict_nt = (g_nontemporal && stream_bytes > 192.0e6) ? 1 : 0;
-      if (D->dict_typed) {
+      if (D->dict_typed) {  // the kernels then never touch the per-row code words
         if ((e = upload(D->drtype, T.rtype.data(), T.rtype.size())) != hipSuccess) return e;
         if ((e = upload(D->drwords, T.rwords.data(), T.rwords.size())) != hipSuccess) return e;
+      } else {
+        if ((e = upload(D->dcodes, T.codes.data(), T.codes.size())) != hipSuccess) return e;
       }
-      if ((e = upload(D->dcodes, T.codes.data(), T.codes.size())) != hipSuccess) return e;
       if ((e = upload(D->doff, T.doff.data(), T.doff.size())) != hipSuccess) return e;
       return upload(D->dval, T.dval.data(), T.dval.size());
     }
