@@ -502,6 +502,37 @@ def test_jacobi_fusions_and_zero_pruning_are_bit_neutral(amg, oracle):
     mg.close()
 
 
+def test_vcycle_nonsymmetric_operator(amg, oracle):
+    """A != A^T: the residual uses the rows of A, the smoothers walk its CSC columns as
+    rows (smoother.hpp:101-117), so the fused residual+restriction kernel and the fused
+    sweep+prolongation kernel run on two different device copies.  Convection-diffusion-like
+    band matrix, true Jacobi and the exact SpGS, every level vector against the oracle."""
+    n = 5000
+    cp = np.zeros(n + 1, dtype=np.int32)
+    ri, va = [], []
+    for j in range(n):                      # column j: rows j-70, j-1, j, j+1, j+70
+        for i, v in ((j - 70, -1.0), (j - 1, -1.5), (j, 5.0), (j + 1, -0.5), (j + 70, -1.0)):
+            if 0 <= i < n:
+                ri.append(i)
+                va.append(v + (0.125 if i == j and j % 3 == 0 else 0.0))
+        cp[j + 1] = len(ri)
+    A = oracle.CSC(n, n, cp, np.array(ri, dtype=np.int32), np.array(va))
+    b = np.sin(0.01 * np.arange(n)) + 2.0
+    L = 4
+    for okind, kind, kw in ((oracle.SM_TRUE_JACOBI, amg.SM_JACOBI, dict(smoother_iters=2, omega=0.6)),
+                            (oracle.SM_SPGS, amg.SM_SPGS, dict(smoother_iters=1))):
+        ref = oracle.Multigrid(A, b, L, smoother=okind, **kw)
+        mg = amg.Multigrid(*csc(A), b, L, smoother=kind, keep_residual=True, **kw)
+        for c in range(3):
+            ref.vcycle()
+            mg.vcycle()
+            for l in range(L):
+                assert np.array_equal(mg.get_soln(l), ref.get_vec(l, "u")), (kind, c, l)
+                assert np.array_equal(mg.get_rhs(l), ref.get_vec(l, "f")), (kind, c, l)
+                assert np.array_equal(mg.get_residual(l), ref.get_vec(l, "r")), (kind, c, l)
+        mg.close()
+
+
 def test_residual_is_private_workspace_by_default(amg, oracle):
     """multigrid.hpp:107: level_to_residual has no getter.  Without keep_residual the fused
     residual+restriction kernel does not store r and the coarsest level skips its (dead)
