@@ -40,7 +40,7 @@ std::string validate(const Sparse& M, const char* name) {
   return "";
 }
 
-Sparse transpose(const Sparse& M) {
+static Sparse transpose_serial(const Sparse& M) {
   Sparse T;
   T.n_outer = M.n_inner;
   T.n_inner = M.n_outer;
@@ -56,6 +56,84 @@ Sparse transpose(const Sparse& M) {
       T.idx[q] = (int32_t)o;
       T.val[q] = M.val[p];
     }
+  return T;
+}
+
+// Threaded form for the large, banded matrices of the hierarchy: the outer range is cut
+// into chunks; a chunk touches a narrow window of inner indices, so its histogram and
+// its scatter cursors are window-sized.  Entries of an output row keep ascending outer
+// order (chunk 0 first, then chunk 1, ...), exactly as in the serial form.
+Sparse transpose(const Sparse& M) {
+  const int64_t nnz = M.nnz();
+  unsigned hw = std::thread::hardware_concurrency();
+  const int T0 = (int)std::min<unsigned>(hw ? hw : 1, 16);
+  if (T0 < 2 || nnz < (1 << 22) || M.n_outer < 64 * T0) return transpose_serial(M);
+  const int nt = T0;
+  struct Chunk {
+    int64_t o0 = 0, o1 = 0;
+    int32_t imin = 0, imax = -1;
+    std::vector<int32_t> cnt;  // per inner index of the window, then the scatter cursor
+  };
+  std::vector<Chunk> ch(nt);
+  auto run = [&](auto&& fn) {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(fn, t);
+    for (auto& x : th) x.join();
+  };
+  // chunks of about equal nnz
+  for (int t = 0; t < nt; ++t) {
+    const int64_t target0 = nnz * t / nt, target1 = nnz * (t + 1) / nt;
+    auto at = [&](int64_t target) {
+      return (int64_t)(std::lower_bound(M.ptr.begin(), M.ptr.end(), (int32_t)target) - M.ptr.begin());
+    };
+    ch[t].o0 = t == 0 ? 0 : std::min<int64_t>(at(target0), M.n_outer);
+    ch[t].o1 = t == nt - 1 ? M.n_outer : std::min<int64_t>(at(target1), M.n_outer);
+  }
+  for (int t = 1; t < nt; ++t) ch[t].o0 = ch[t - 1].o1;
+  run([&](int t) {
+    Chunk& c = ch[t];
+    int32_t lo = INT32_MAX, hi = -1;
+    for (int32_t p = M.ptr[c.o0]; p < M.ptr[c.o1]; ++p) {
+      lo = std::min(lo, M.idx[p]);
+      hi = std::max(hi, M.idx[p]);
+    }
+    c.imin = lo;
+    c.imax = hi;
+    if (hi < lo) return;
+    c.cnt.assign((size_t)hi - lo + 1, 0);
+    for (int32_t p = M.ptr[c.o0]; p < M.ptr[c.o1]; ++p) c.cnt[M.idx[p] - lo]++;
+  });
+  int64_t windows = 0;
+  for (auto& c : ch) windows += (int64_t)c.cnt.size();
+  if (windows > 4 * M.n_inner + (1 << 20)) return transpose_serial(M);  // not banded: too much scratch
+  Sparse T;
+  T.n_outer = M.n_inner;
+  T.n_inner = M.n_outer;
+  T.ptr.assign(T.n_outer + 1, 0);
+  T.idx.resize(nnz);
+  T.val.resize(nnz);
+  for (auto& c : ch)
+    for (size_t k = 0; k < c.cnt.size(); ++k) T.ptr[(size_t)c.imin + k + 1] += c.cnt[k];
+  for (int64_t o = 0; o < T.n_outer; ++o) T.ptr[o + 1] += T.ptr[o];
+  {  // cursors: chunk t starts behind what the chunks before it put into the row
+    std::vector<int32_t> filled(T.n_outer, 0);
+    for (auto& c : ch)
+      for (size_t k = 0; k < c.cnt.size(); ++k) {
+        const size_t i = (size_t)c.imin + k;
+        const int32_t n_here = c.cnt[k];
+        c.cnt[k] = T.ptr[i] + filled[i];
+        filled[i] += n_here;
+      }
+  }
+  run([&](int t) {
+    Chunk& c = ch[t];
+    for (int64_t o = c.o0; o < c.o1; ++o)
+      for (int32_t p = M.ptr[o]; p < M.ptr[o + 1]; ++p) {
+        const int32_t q = c.cnt[M.idx[p] - c.imin]++;
+        T.idx[q] = (int32_t)o;
+        T.val[q] = M.val[p];
+      }
+  });
   return T;
 }
 
@@ -207,6 +285,93 @@ void to_sell64(const Sparse& M, Sell64* S) {
   }
 }
 
+namespace {
+// rows [r0, r1) with a chunk-local pair table (codes are local numbers)
+struct DictChunk {
+  std::vector<int32_t> doff;
+  std::vector<double> dval;
+  std::vector<uint64_t> words;  // chunk-local distinct rows (row types), `nw` words each
+  bool ok = true, typed = true;
+};
+void dict_encode_rows(const Sparse& M, int64_t diag_shift, const int32_t* rowid, int64_t r0,
+                      int64_t r1, int nw, uint64_t* codes, DictChunk* C) {
+  std::map<std::pair<int64_t, uint64_t>, int> table;
+  int prev[16];  // codes of the previous row, tried first (interior rows repeat)
+  for (int j = 0; j < 16; ++j) prev[j] = -1;
+  for (int64_t r = r0; r < r1; ++r) {
+    uint64_t w[2] = {~(uint64_t)0, ~(uint64_t)0};
+    int j = 0;
+    for (int32_t q = M.ptr[r]; q < M.ptr[r + 1]; ++q, ++j) {
+      const int64_t d = (int64_t)M.idx[q] - (rowid ? (int64_t)rowid[r] : r + diag_shift);
+      if (d < INT32_MIN / 2 || d > INT32_MAX / 2) { C->ok = false; return; }
+      uint64_t bits;
+      std::memcpy(&bits, &M.val[q], 8);
+      int code = prev[j];
+      bool hit = false;
+      if (code >= 0 && C->doff[code] == (int32_t)d) {
+        uint64_t tb;
+        std::memcpy(&tb, &C->dval[code], 8);
+        hit = tb == bits;
+      }
+      if (!hit) {
+        auto key = std::make_pair(d, bits);
+        auto it = table.find(key);
+        if (it == table.end()) {
+          if (C->doff.size() >= 255) { C->ok = false; return; }
+          code = (int)C->doff.size();
+          table.emplace(key, code);
+          C->doff.push_back((int32_t)d);
+          C->dval.push_back(M.val[q]);
+        } else {
+          code = it->second;
+        }
+        prev[j] = code;
+      }
+      w[j >> 3] = (w[j >> 3] & ~((uint64_t)0xFF << (8 * (j & 7)))) | ((uint64_t)code << (8 * (j & 7)));
+    }
+    codes[(size_t)r * nw] = w[0];
+    if (nw == 2) codes[(size_t)r * 2 + 1] = w[1];
+  }
+}
+// local code numbers -> global ones in every code word of rows [r0, r1)
+void dict_remap_rows(int64_t r0, int64_t r1, int nw, const uint8_t* lut, uint64_t* codes) {
+  for (size_t k = (size_t)r0 * nw; k < (size_t)r1 * nw; ++k) {
+    uint64_t w = codes[k], o = 0;
+    for (int b = 0; b < 8; ++b) o |= (uint64_t)lut[(w >> (8 * b)) & 0xFF] << (8 * b);
+    codes[k] = o;
+  }
+}
+void dict_type_rows(int64_t r0, int64_t r1, int nw, const uint64_t* codes, uint8_t* rtype,
+                    DictChunk* C) {
+  std::map<std::pair<uint64_t, uint64_t>, int> types;
+  int last = -1;
+  std::pair<uint64_t, uint64_t> last_key(0, 0);
+  for (int64_t r = r0; r < r1; ++r) {
+    const std::pair<uint64_t, uint64_t> key(codes[(size_t)r * nw], nw == 2 ? codes[(size_t)r * 2 + 1] : 0);
+    int t;
+    if (last >= 0 && key == last_key) {
+      t = last;
+    } else {
+      auto it = types.find(key);
+      if (it == types.end()) {
+        if (types.size() >= 255) { C->typed = false; return; }
+        t = (int)types.size();
+        types.emplace(key, t);
+        C->words.push_back(key.first);
+        if (nw == 2) C->words.push_back(key.second);
+      } else {
+        t = it->second;
+      }
+      last = t;
+      last_key = key;
+    }
+    rtype[(size_t)r] = (uint8_t)t;
+  }
+}
+}  // namespace
+
+// Threaded over row chunks: every chunk numbers its pairs (and then its distinct rows)
+// locally, the tables are merged in chunk order and the codes renumbered.
 bool to_dict(const Sparse& M, int64_t diag_shift, DictMat* D, const int32_t* rowid) {
   const int64_t n = M.n_outer;
   int32_t mw = 0;
@@ -220,78 +385,82 @@ bool to_dict(const Sparse& M, int64_t diag_shift, DictMat* D, const int32_t* row
   D->n = n;
   D->max_width = mw;
   D->words = mw > 8 ? 2 : 1;
+  const int nw = D->words;
   D->doff.clear();
   D->dval.clear();
-  D->codes.assign((size_t)n * D->words, ~(uint64_t)0);
-  std::map<std::pair<int64_t, uint64_t>, int> table;
-  int prev[16];  // codes of the previous row, tried first (interior rows repeat)
-  for (int j = 0; j < 16; ++j) prev[j] = -1;
-  for (int64_t r = 0; r < n; ++r) {
-    uint64_t w[2] = {~(uint64_t)0, ~(uint64_t)0};
-    int j = 0;
-    for (int32_t q = M.ptr[r]; q < M.ptr[r + 1]; ++q, ++j) {
-      const int64_t d = (int64_t)M.idx[q] - (rowid ? (int64_t)rowid[r] : r + diag_shift);
-      if (d < INT32_MIN / 2 || d > INT32_MAX / 2) return false;
+  D->rtype.clear();
+  D->rwords.clear();
+  D->codes.assign((size_t)n * nw, ~(uint64_t)0);
+  unsigned hw = std::thread::hardware_concurrency();
+  const int nt = n < (1 << 20) ? 1 : (int)std::min<unsigned>(hw ? hw : 1, 16);
+  std::vector<DictChunk> ch(nt);
+  auto run = [&](auto&& fn) {
+    if (nt == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(fn, t);
+    for (auto& x : th) x.join();
+  };
+  auto lo = [&](int t) { return n * t / nt; };
+  run([&](int t) { dict_encode_rows(M, diag_shift, rowid, lo(t), lo(t + 1), nw, D->codes.data(), &ch[t]); });
+  // merge the pair tables
+  std::map<std::pair<int32_t, uint64_t>, int> table;
+  std::vector<std::vector<uint8_t>> lut(nt, std::vector<uint8_t>(256, 0xFF));
+  for (int t = 0; t < nt; ++t) {
+    if (!ch[t].ok) return false;
+    for (size_t k = 0; k < ch[t].doff.size(); ++k) {
       uint64_t bits;
-      std::memcpy(&bits, &M.val[q], 8);
-      int code = prev[j];
-      bool hit = false;
-      if (code >= 0 && D->doff[code] == (int32_t)d) {
-        uint64_t tb;
-        std::memcpy(&tb, &D->dval[code], 8);
-        hit = tb == bits;
+      std::memcpy(&bits, &ch[t].dval[k], 8);
+      auto key = std::make_pair(ch[t].doff[k], bits);
+      auto it = table.find(key);
+      int code;
+      if (it == table.end()) {
+        if (D->doff.size() >= 255) return false;
+        code = (int)D->doff.size();
+        table.emplace(key, code);
+        D->doff.push_back(ch[t].doff[k]);
+        D->dval.push_back(ch[t].dval[k]);
+      } else {
+        code = it->second;
       }
-      if (!hit) {
-        auto key = std::make_pair(d, bits);
-        auto it = table.find(key);
-        if (it == table.end()) {
-          if (D->doff.size() >= 255) return false;
-          code = (int)D->doff.size();
-          table.emplace(key, code);
-          D->doff.push_back((int32_t)d);
-          D->dval.push_back(M.val[q]);
-        } else {
-          code = it->second;
-        }
-        prev[j] = code;
-      }
-      w[j >> 3] = (w[j >> 3] & ~((uint64_t)0xFF << (8 * (j & 7)))) | ((uint64_t)code << (8 * (j & 7)));
+      lut[t][k] = (uint8_t)code;
     }
-    D->codes[(size_t)r * D->words] = w[0];
-    if (D->words == 2) D->codes[(size_t)r * 2 + 1] = w[1];
   }
+  if (nt > 1) run([&](int t) { dict_remap_rows(lo(t), lo(t + 1), nw, lut[t].data(), D->codes.data()); });
   // row types
   D->rtype.assign((size_t)n, 255);
-  D->rwords.assign((size_t)256 * D->words, ~(uint64_t)0);
+  run([&](int t) { dict_type_rows(lo(t), lo(t + 1), nw, D->codes.data(), D->rtype.data(), &ch[t]); });
+  D->rwords.assign((size_t)256 * nw, ~(uint64_t)0);
   std::map<std::pair<uint64_t, uint64_t>, int> types;
-  int last = -1;
-  std::pair<uint64_t, uint64_t> last_key(0, 0);
-  for (int64_t r = 0; r < n; ++r) {
-    const std::pair<uint64_t, uint64_t> key(D->codes[(size_t)r * D->words],
-                                            D->words == 2 ? D->codes[(size_t)r * 2 + 1] : 0);
-    int t;
-    if (last >= 0 && key == last_key) {
-      t = last;
-    } else {
+  bool typed = true;
+  for (int t = 0; t < nt && typed; ++t) {
+    if (!ch[t].typed) { typed = false; break; }
+    std::fill(lut[t].begin(), lut[t].end(), 0xFF);
+    for (size_t k = 0; k * nw < ch[t].words.size(); ++k) {
+      const std::pair<uint64_t, uint64_t> key(ch[t].words[k * nw], nw == 2 ? ch[t].words[k * 2 + 1] : 0);
       auto it = types.find(key);
+      int ty;
       if (it == types.end()) {
-        if (types.size() >= 255) {  // too many distinct rows: first level only
-          D->rtype.clear();
-          D->rwords.clear();
-          return true;
-        }
-        t = (int)types.size();
-        types.emplace(key, t);
-        D->rwords[(size_t)t * D->words] = key.first;
-        if (D->words == 2) D->rwords[(size_t)t * 2 + 1] = key.second;
+        if (types.size() >= 255) { typed = false; break; }
+        ty = (int)types.size();
+        types.emplace(key, ty);
+        D->rwords[(size_t)ty * nw] = key.first;
+        if (nw == 2) D->rwords[(size_t)ty * 2 + 1] = key.second;
       } else {
-        t = it->second;
+        ty = it->second;
       }
-      last = t;
-      last_key = key;
+      lut[t][k] = (uint8_t)ty;
     }
-    D->rtype[(size_t)r] = (uint8_t)t;
   }
+  if (!typed) {  // too many distinct rows: first level only
+    D->rtype.clear();
+    D->rwords.clear();
+    return true;
+  }
+  if (nt > 1)
+    run([&](int t) {
+      const uint8_t* l = lut[t].data();
+      for (int64_t r = lo(t); r < lo(t + 1); ++r) D->rtype[(size_t)r] = l[D->rtype[(size_t)r]];
+    });
   return true;
 }
 

@@ -84,6 +84,8 @@ def test_dictionary_coding_round_trips_on_the_host(amg, oracle):
             assert 1 <= pairs <= 64 and 1 <= types <= 64 and words in (1, 2), (n, dim, l, got)
     cp, ri, v = amg.laplacian(64)
     assert amg.dict_probe(cp, ri, v, 64 * 64) == (5, 9, 1)     # 2-D 5-point: 5 pairs, 9 distinct rows
+    cp, ri, v = amg.laplacian(1024)                             # >= 2^20 rows: the threaded encoder
+    assert amg.dict_probe(cp, ri, v, 1024 * 1024) == (5, 9, 1)
     # a halo-extended local block (multi-GPU): columns shifted by the halo width
     rows = 40
     rp = np.arange(0, 3 * rows + 1, 3, dtype=np.int32)
