@@ -846,6 +846,11 @@ static bool aligned16(const void* a, const void* b, const void* c) {
   return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
            reinterpret_cast<uintptr_t>(c)) & 15) == 0;
 }
+// The contiguous-run-per-XCD tile order pays where the level lives in the caches (levels
+// 2+ of the 4096^2 hierarchy: -1..3 us per launch); on the streamed levels beyond the
+// Infinity Cache the plain order is faster (level 0: 91 vs 94 us per sweep, fused
+// residual 108 vs 114 us), although it fetches x 2x at the L2 -- measured per level.
+static int dict_xcd_map(const DictRef& D) { return (g_xcd_map && !D.nt) ? 1 : 0; }
 // two rows per lane need 16-byte aligned f / out / codes (vector lane accesses)
 static bool dict_two_rows(int64_t n, const DictRef& D, const void* f, const void* out) {
   return g_dict_rows_per_lane == 2 && n >= 4096 && aligned16(f, out, D.rtype ? nullptr : D.codes) &&
@@ -865,7 +870,7 @@ hipError_t launch_dict_resid_restrict(int64_t n, const DictRef& D, const double*
     hipLaunchKernelGGL((dict_resid_restrict_kernel<decltype(W)::value, decltype(U)::value,
                                                    decltype(NTF)::value, decltype(RR)::value>),
                        dim3(tiles), dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff,
-                       D.dval, D.ntab, x, f, r_out, (int)nH, fH, diagH, uH1, uH0, omega, g_xcd_map);
+                       D.dval, D.ntab, x, f, r_out, (int)nH, fH, diagH, uH1, uH0, omega, dict_xcd_map(D));
   });
 }
 hipError_t launch_dict_jacobi_prolong(int64_t n, const DictRef& D, const double* x,
@@ -882,7 +887,7 @@ hipError_t launch_dict_jacobi_prolong(int64_t n, const DictRef& D, const double*
     hipLaunchKernelGGL((dict_jacobi_prolong_kernel<decltype(W)::value, decltype(U)::value,
                                                    decltype(NTF)::value, decltype(RR)::value>),
                        dim3(tiles), dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff,
-                       D.dval, D.ntab, x, f, out, omega, (int)n_h, uh, g_xcd_map);
+                       D.dval, D.ntab, x, f, out, omega, (int)n_h, uh, dict_xcd_map(D));
   });
 }
 void set_xcd_mapping(int on) { g_xcd_map = on ? 1 : 0; }
@@ -896,7 +901,7 @@ static hipError_t launch_dict_mode(int64_t n, const DictRef& D, const double* x,
     hipLaunchKernelGGL((dict_kernel<MODE, decltype(W)::value, decltype(U)::value,
                                     decltype(NTF)::value, decltype(RR)::value>),
                        dim3(tiles), dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff,
-                       D.dval, D.ntab, x, f, out, omega, (int)dshift, g_xcd_map);
+                       D.dval, D.ntab, x, f, out, omega, (int)dshift, dict_xcd_map(D));
   });
 }
 hipError_t launch_dict(int mode, int64_t n, const DictRef& D, const double* x, const double* f,
