@@ -18,6 +18,8 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 //    6 = 2 + 64 B staged + barrier + lookups
 //    7 = 2 + lookups in a wave-private table, no workgroup barrier
 //    8 = 6, with the gathers depending on the looked-up value (offset from the table)
+//    9 = the tile's three x windows staged in LDS with dense 16-byte loads (3 per lane
+//        instead of 10 gathers), stencil read from LDS, weights looked up as in 6
 template <int V>
 __global__ __launch_bounds__(256) void k(int n, const double* __restrict__ f, const double* x,
                                          const uint8_t* __restrict__ ty,
@@ -43,7 +45,42 @@ __global__ __launch_bounds__(256) void k(int n, const double* __restrict__ f, co
     __builtin_amdgcn_wave_barrier();
   }
   double acc[2];
-  if (V < 2) {
+  if (V == 9) {
+    __shared__ double xs[3][528];
+    const int t0 = blockIdx.x * 512;
+    const int lo[3] = {-4096, -8, 4096};   // window starts (even, 16-byte aligned)
+    {
+      const int i = threadIdx.x * 2;
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const int g = t0 + lo[kk] + i;
+        f64x2 v2 = {0.0, 0.0};
+        if (g >= 0 && g + 1 < n) v2 = *reinterpret_cast<const f64x2*>(x + g);
+        xs[kk][i] = v2.x;
+        xs[kk][i + 1] = v2.y;
+      }
+      if (threadIdx.x < 8) {   // the middle window is 528 wide
+        const int g = t0 + lo[1] + 512 + i;
+        f64x2 v2 = {0.0, 0.0};
+        if (g >= 0 && g + 1 < n) v2 = *reinterpret_cast<const f64x2*>(x + g);
+        xs[1][512 + i] = v2.x;
+        xs[1][512 + i + 1] = v2.y;
+      }
+      if (threadIdx.x < 8) tab[threadIdx.x] = tabg[threadIdx.x];
+    }
+    __syncthreads();
+    const int l0 = threadIdx.x * 2;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int l = l0 + r;
+      const double w = tab[((t >> (8 * r)) & 0x7)];
+      acc[r] = w * xs[0][l];
+      acc[r] += w * xs[1][l + 7];
+      acc[r] += w * xs[1][l + 8];
+      acc[r] += w * xs[1][l + 9];
+      acc[r] += w * xs[2][l];
+    }
+  } else if (V < 2) {
     const f64x2 xi = *reinterpret_cast<const f64x2*>(x + row0);
     acc[0] = xi.x; acc[1] = xi.y;
   } else {
@@ -112,17 +149,18 @@ int main() {
   hipMemset(xb, 0, (size_t)n * 8);
   hipMemset(ty, 0, (size_t)n);
   hipMemset(tab, 0, 1280 * 8);
-  const double us[9] = {run<0>(n, f, xa, xb, ty, tab), run<1>(n, f, xa, xb, ty, tab),
+  const double us[10] = {run<0>(n, f, xa, xb, ty, tab), run<1>(n, f, xa, xb, ty, tab),
                         run<2>(n, f, xa, xb, ty, tab), run<3>(n, f, xa, xb, ty, tab),
                         run<4>(n, f, xa, xb, ty, tab), run<5>(n, f, xa, xb, ty, tab),
                         run<6>(n, f, xa, xb, ty, tab), run<7>(n, f, xa, xb, ty, tab),
-                        run<8>(n, f, xa, xb, ty, tab)};
-  const char* name[9] = {"stream triad out = f + s*x (24 B/row)", "+ 1 B/row of row types (25 B/row)",
+                        run<8>(n, f, xa, xb, ty, tab), run<9>(n, f, xa, xb, ty, tab)};
+  const char* name[10] = {"stream triad out = f + s*x (24 B/row)", "+ 1 B/row of row types (25 B/row)",
                          "x as five 8-byte gathers per row", "+ 10 KB LDS table per workgroup, lookups",
                          "+ fp64 division per row", "gathers + barrier only (64 B staged)",
                          "gathers + 64 B staged + barrier + lookups", "gathers + wave-private table, no barrier",
-                         "as before, gather address from the table"};
-  for (int v = 0; v < 9; ++v)
+                         "as before, gather address from the table",
+                         "x windows staged in LDS with 16-byte loads"};
+  for (int v = 0; v < 10; ++v)
     std::printf("%-46s %7.1f us  %5.2f TB/s of the %d B/row\n", name[v], us[v],
                 (v == 0 ? 24.0 : 25.0) * n / us[v] / 1e6, v == 0 ? 24 : 25);
   return 0;
