@@ -18,6 +18,8 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 //    6 = 2 + 64 B staged + barrier + lookups
 //    7 = 2 + lookups in a wave-private table, no workgroup barrier
 //    8 = 6, with the gathers depending on the looked-up value (offset from the table)
+//   10 = 2 with a 2-D patch of rows per workgroup (8 grid lines x 64 columns) instead of
+//        512 consecutive rows: the +-4096 neighbours are rows of the same workgroup
 //    9 = the tile's three x windows staged in LDS with dense 16-byte loads (3 per lane
 //        instead of 10 gathers), stencil read from LDS, weights looked up as in 6
 template <int V>
@@ -26,7 +28,13 @@ __global__ __launch_bounds__(256) void k(int n, const double* __restrict__ f, co
                                          const double* __restrict__ tabg, double* __restrict__ out,
                                          double s) {
   __shared__ double tab[1280];
-  const int row0 = (blockIdx.x * 256 + threadIdx.x) * 2;
+  int row0 = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (V == 10) {  // tile -> (column block of 64, block of 8 lines); wave w owns lines 2w, 2w+1
+    const int S = 4096, nb = S / 64;
+    const int jb = blockIdx.x % nb, kb = blockIdx.x / nb;
+    const int line = kb * 8 + ((int)threadIdx.x >> 5);          // 32 lanes x 2 rows per line
+    row0 = line * S + jb * 64 + ((int)threadIdx.x & 31) * 2;
+  }
   if (row0 + 1 >= n) return;
   const f64x2 fi = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(f + row0));
   uint32_t t = 0;
@@ -149,18 +157,20 @@ int main() {
   hipMemset(xb, 0, (size_t)n * 8);
   hipMemset(ty, 0, (size_t)n);
   hipMemset(tab, 0, 1280 * 8);
-  const double us[10] = {run<0>(n, f, xa, xb, ty, tab), run<1>(n, f, xa, xb, ty, tab),
+  const double us[11] = {run<0>(n, f, xa, xb, ty, tab), run<1>(n, f, xa, xb, ty, tab),
                         run<2>(n, f, xa, xb, ty, tab), run<3>(n, f, xa, xb, ty, tab),
                         run<4>(n, f, xa, xb, ty, tab), run<5>(n, f, xa, xb, ty, tab),
                         run<6>(n, f, xa, xb, ty, tab), run<7>(n, f, xa, xb, ty, tab),
-                        run<8>(n, f, xa, xb, ty, tab), run<9>(n, f, xa, xb, ty, tab)};
-  const char* name[10] = {"stream triad out = f + s*x (24 B/row)", "+ 1 B/row of row types (25 B/row)",
+                        run<8>(n, f, xa, xb, ty, tab), run<9>(n, f, xa, xb, ty, tab),
+                        run<10>(n, f, xa, xb, ty, tab)};
+  const char* name[11] = {"stream triad out = f + s*x (24 B/row)", "+ 1 B/row of row types (25 B/row)",
                          "x as five 8-byte gathers per row", "+ 10 KB LDS table per workgroup, lookups",
                          "+ fp64 division per row", "gathers + barrier only (64 B staged)",
                          "gathers + 64 B staged + barrier + lookups", "gathers + wave-private table, no barrier",
                          "as before, gather address from the table",
-                         "x windows staged in LDS with 16-byte loads"};
-  for (int v = 0; v < 10; ++v)
+                         "x windows staged in LDS with 16-byte loads",
+                         "five gathers, 8 lines x 64 columns per workgroup"};
+  for (int v = 0; v < 11; ++v)
     std::printf("%-46s %7.1f us  %5.2f TB/s of the %d B/row\n", name[v], us[v],
                 (v == 0 ? 24.0 : 25.0) * n / us[v] / 1e6, v == 0 ? 24 : 25);
   return 0;
