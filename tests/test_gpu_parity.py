@@ -587,6 +587,40 @@ def test_fused_level_kernels_at_tile_boundaries(amg, oracle):
         mg.close()
 
 
+def test_vcycle_random_band_operators(amg, oracle):
+    """Seeded sweep over sizes, band offsets, sweep counts and level counts: symmetric band
+    operators with a second band at +-k (the flat-index picture of a 2-D stencil with line
+    length k), true Jacobi, every level's u and f against the oracle bit for bit."""
+    rng = np.random.default_rng(20251004)
+    for case in range(14):
+        n = int(rng.integers(300, 20000))
+        k = int(rng.integers(3, 200))
+        L = int(rng.integers(2, 6))
+        sweeps = int(rng.integers(1, 4))
+        while (n >> (L - 1)) < 8:
+            L -= 1
+        cp = np.zeros(n + 1, dtype=np.int32)
+        ri, va = [], []
+        for j in range(n):
+            for i, v in ((j - k, -1.0), (j - 1, -1.0 if j % k else 0.0), (j, 4.0 + 0.5 * (j % 2)),
+                         (j + 1, -1.0 if (j + 1) % k else 0.0), (j + k, -1.0)):
+                if 0 <= i < n and v != 0.0:
+                    ri.append(i)
+                    va.append(v)
+            cp[j + 1] = len(ri)
+        A = oracle.CSC(n, n, cp, np.array(ri, dtype=np.int32), np.array(va))
+        b = 1.0 + rng.random(n)
+        ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=sweeps, omega=0.55)
+        mg = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=sweeps, omega=0.55)
+        for c in range(2):
+            ref.vcycle()
+            mg.vcycle()
+        for l in range(L):
+            assert np.array_equal(mg.get_soln(l), ref.get_vec(l, "u")), (case, n, k, L, sweeps, l)
+            assert np.array_equal(mg.get_rhs(l), ref.get_vec(l, "f")), (case, n, k, L, sweeps, l)
+        mg.close()
+
+
 def test_partitioned_coarse_solve(amg, oracle, mats):
     """opt.fast_coarse_solve: the banded LDL^T solve cut into partitions that are solved
     in parallel and coupled by a short boundary recurrence.  Same direct solve as the
