@@ -1,74 +1,72 @@
-// Drop-in for include/amg/interpolator.hpp.
+// interpolator.hpp -- AMG::InterpolatorBase / AMG::LinearInterpolator of the drop-in.
+//
+// Same public interface as the reference's interpolator.hpp (constructors, the pure
+// virtual make_operators(n_h, n_H, level), prolongation / restriction, the P / R getters
+// and setters); the products run on the device through the C ABI.  Inside the V-cycle
+// the operators of LinearInterpolator are recognised and replaced by matrix-free kernels.
 #pragma once
+#include <array>
 #include <vector>
 
 #include <amg/eigen_lite.hpp>
 
 namespace AMG {
 
-// reference interpolator.hpp:15-87
 template <class EleType>
 class InterpolatorBase {
-  std::vector<Eigen::SparseMatrix<EleType>> level_to_P;
-  std::vector<Eigen::SparseMatrix<EleType>> level_to_R;
+  using Sparse = Eigen::SparseMatrix<EleType>;
+  using Vector = Eigen::Matrix<EleType, -1, 1>;
 
-  static Eigen::Matrix<EleType, -1, 1> apply(const Eigen::SparseMatrix<EleType>& M,
-                                             const Eigen::Matrix<EleType, -1, 1>& v) {
+  std::vector<Sparse> prolong_;   // level l -> P_l (fine x coarse)
+  std::vector<Sparse> restrict_;  // level l -> R_l (coarse x fine)
+
+  // M * v as one device SpMV (interpolator.hpp:52-56 and :64-68 of the reference)
+  static Vector device_product(const Sparse& M, const Vector& v) {
     static_assert(sizeof(EleType) == sizeof(double), "the MI355X path is fp64 only");
-    const Eigen::SparseMatrix<EleType> C = detail::compressed(M);
-    Eigen::Matrix<EleType, -1, 1> result(C.rows());
-    detail::check(amg_hip_spmv(C.rows(), C.cols(), C.outerIndexPtr(), C.innerIndexPtr(),
-                               C.valuePtr(), v.data(), result.data()));
-    return result;
+    const Sparse packed = detail::compressed(M);
+    Vector out(packed.rows());
+    detail::check(amg_hip_spmv(packed.rows(), packed.cols(), packed.outerIndexPtr(),
+                               packed.innerIndexPtr(), packed.valuePtr(), v.data(), out.data()));
+    return out;
   }
 
  public:
-  InterpolatorBase(size_t n_levels) {
-    level_to_P.resize(n_levels - 1);
-    level_to_R.resize(n_levels - 1);
-  }
-  InterpolatorBase() {}
-  virtual ~InterpolatorBase() {}
+  InterpolatorBase() = default;
+  explicit InterpolatorBase(size_t n_levels) : prolong_(n_levels - 1), restrict_(n_levels - 1) {}
+  virtual ~InterpolatorBase() = default;
 
+  // fills P and R of `level` for a fine level of n_h_dofs and a coarse one of n_H_dofs
   virtual void make_operators(size_t n_h_dofs, size_t n_H_dofs, size_t level) = 0;
 
-  // P_level * v and R_level * v, on the device (interpolator.hpp:52-56, :64-68)
-  Eigen::Matrix<EleType, -1, 1> prolongation(const Eigen::Matrix<EleType, -1, 1>& v, size_t level) {
-    return apply(get_P(level), v);
-  }
-  Eigen::Matrix<EleType, -1, 1> restriction(const Eigen::Matrix<EleType, -1, 1>& v, size_t level) {
-    return apply(get_R(level), v);
-  }
+  Vector prolongation(const Vector& v, size_t level) { return device_product(prolong_[level], v); }
+  Vector restriction(const Vector& v, size_t level) { return device_product(restrict_[level], v); }
 
-  const Eigen::SparseMatrix<EleType>& get_P(size_t level) const { return level_to_P[level]; }
-  const Eigen::SparseMatrix<EleType>& get_R(size_t level) const { return level_to_R[level]; }
-  void set_level_to_P(size_t level, Eigen::SparseMatrix<EleType>& P) { level_to_P[level] = P; }
-  void set_level_to_R(size_t level, Eigen::SparseMatrix<EleType>& R) { level_to_R[level] = R; }
-  size_t n_operator_levels() const { return level_to_P.size(); }
+  const Sparse& get_P(size_t level) const { return prolong_[level]; }
+  const Sparse& get_R(size_t level) const { return restrict_[level]; }
+  void set_level_to_P(size_t level, Sparse& P) { prolong_[level] = P; }
+  void set_level_to_R(size_t level, Sparse& R) { restrict_[level] = R; }
+  size_t n_operator_levels() const { return prolong_.size(); }
 };
 
-// reference interpolator.hpp:98-142
+// 1-D linear interpolation in the flat index: coarse dof c feeds fine rows 2c, 2c+1, 2c+2
+// with weights 1/2, 1, 1/2 (rows past the fine level are dropped); R is P transposed.
 template <class EleType>
 class LinearInterpolator : public InterpolatorBase<EleType> {
-  const size_t n_elements_per_columns = 3;
-
  public:
   using InterpolatorBase<EleType>::InterpolatorBase;
 
   void make_operators(size_t n_h_dofs, size_t n_H_dofs, size_t level) override {
+    static const std::array<EleType, 3> weight = {EleType(0.5), EleType(1.0), EleType(0.5)};
+    std::vector<Eigen::Triplet<EleType>> entries;
+    entries.reserve(weight.size() * n_H_dofs);
+    for (size_t coarse = 0; coarse < n_H_dofs; ++coarse)
+      for (size_t k = 0; k < weight.size(); ++k) {
+        const size_t fine = 2 * coarse + k;
+        if (fine < n_h_dofs) entries.emplace_back(fine, coarse, weight[k]);
+      }
     Eigen::SparseMatrix<EleType> P(n_h_dofs, n_H_dofs);
-    std::vector<Eigen::Triplet<EleType>> P_coefficients;
-    P_coefficients.reserve(n_H_dofs * n_elements_per_columns);
-    size_t i = 0;
-    for (size_t j = 0; j < n_H_dofs; ++j) {
-      if (i < n_h_dofs) P_coefficients.push_back(Eigen::Triplet<EleType>(i, j, 0.5));
-      if (i + 1 < n_h_dofs) P_coefficients.push_back(Eigen::Triplet<EleType>(i + 1, j, 1.0));
-      if (i + 2 < n_h_dofs) P_coefficients.push_back(Eigen::Triplet<EleType>(i + 2, j, 0.5));
-      i += n_elements_per_columns - 1;
-    }
-    P.setFromTriplets(P_coefficients.begin(), P_coefficients.end());
-    Eigen::SparseMatrix<EleType> R(n_H_dofs, n_h_dofs);
-    R = P.transpose();
+    P.setFromTriplets(entries.begin(), entries.end());
+    Eigen::SparseMatrix<EleType> R = P.transpose();
     this->set_level_to_P(level, P);
     this->set_level_to_R(level, R);
   }
