@@ -653,6 +653,65 @@ __global__ __launch_bounds__(256) void dict_kernel(
 // :268 on level l+1 whose u is zero): r = f - A u is written, f_H = R r is written, and
 // the from-zero sweep of the coarse level (jacobi_from_zero_kernel) is written to uH1.
 // Other smoothers (uH1 == nullptr): the coarse u is zero-filled instead (uH0, :278).
+// restriction of a tile's residuals rs[0 .. 256 R) (rows tile * (256 R - 2) ...) and, when
+// uH1 is given, the first coarse Jacobi sweep from zero; else the coarse u is zero-filled
+template <int R>
+__device__ __forceinline__ void dict_restrict_tail(int tile, int n, const double* rs, int nH,
+                                                   double* __restrict__ fH,
+                                                   const double* __restrict__ diagH,
+                                                   double* __restrict__ uH1,
+                                                   double* __restrict__ uH0, double omega) {
+  for (int q = threadIdx.x; q < 128 * R - 1; q += 256) {
+    const int j = tile * (128 * R - 1) + q;
+    if (j >= nH) break;
+    const int64_t i = 2 * (int64_t)j;  // linear_restrict_kernel, same guards and order
+    double sum = 0.0;
+    if (i < n) sum += 0.5 * rs[2 * q];
+    if (i + 1 < n) sum += 1.0 * rs[2 * q + 1];
+    if (i + 2 < n) sum += 0.5 * rs[2 * q + 2];
+    fH[j] = sum;
+    if (uH1) {
+      const double xi = 0.0, acc = 0.0;  // jacobi_from_zero_kernel
+      const double d = diagH[j];
+      uH1[j] = (d == 0.0) ? xi : xi + omega * ((sum - acc) / d - xi);
+    } else {
+      uH0[j] = 0.0;  // multigrid.hpp:278
+    }
+  }
+}
+// prolongation of a tile's new coarse values rs[] into the finer level:
+// uh_out[2j] = uh_in[2j] + (0.5 u_H[j-1] + 0.5 u_H[j]), uh_out[2j+1] = uh_in[2j+1] + u_H[j]
+// (linear_prolong_add2_kernel).  The tile prolongs the coarse points q = 1 .. stride (q = 0
+// too in the first tile); j = n is the virtual point whose fine rows only receive the left
+// neighbour / + 0.0.  uh_in == uh_out is the in-place form.
+template <int R>
+__device__ __forceinline__ void dict_prolong_tail(int tile, int n, const double* rs, int n_h,
+                                                  const double* uh_in, double* uh_out) {
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  const int stride = 256 * R - 2;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int q = (int)threadIdx.x * R + r;
+    const int j = tile * stride + q;
+    if ((q == 0 && tile != 0) || q > stride || j > n) continue;
+    double t0 = 0.0, t1 = 0.0;
+    const double b = (j < n) ? rs[q] : 0.0;
+    if (j >= 1 && j - 1 < n) t0 += 0.5 * rs[q - 1];
+    if (j < n) {
+      t0 += 0.5 * b;
+      t1 += 1.0 * b;
+    }
+    const int64_t i = 2 * (int64_t)j;
+    if (i + 1 < n_h) {
+      f64x2 u = *reinterpret_cast<const f64x2*>(uh_in + i);
+      u.x = u.x + t0;
+      u.y = u.y + t1;
+      *reinterpret_cast<f64x2*>(uh_out + i) = u;
+    } else if (i < n_h) {
+      uh_out[i] = uh_in[i] + t0;
+    }
+  }
+}
 template <int WORDS, int UN, bool NT, int R>
 __global__ __launch_bounds__(256) void dict_resid_restrict_kernel(
     int n, const uint64_t* __restrict__ codes, const uint8_t* __restrict__ rtype,
@@ -677,23 +736,7 @@ __global__ __launch_bounds__(256) void dict_resid_restrict_kernel(
 #pragma unroll
   for (int r = 0; r < R; ++r) rs[threadIdx.x * R + r] = s.live[r] ? res[r] : 0.0;
   __syncthreads();
-  for (int q = threadIdx.x; q < 128 * R - 1; q += 256) {
-    const int j = tile * (128 * R - 1) + q;
-    if (j >= nH) break;
-    const int64_t i = 2 * (int64_t)j;  // linear_restrict_kernel, same guards and order
-    double sum = 0.0;
-    if (i < n) sum += 0.5 * rs[2 * q];
-    if (i + 1 < n) sum += 1.0 * rs[2 * q + 1];
-    if (i + 2 < n) sum += 0.5 * rs[2 * q + 2];
-    fH[j] = sum;
-    if (uH1) {
-      const double xi = 0.0, acc = 0.0;  // jacobi_from_zero_kernel
-      const double d = diagH[j];
-      uH1[j] = (d == 0.0) ? xi : xi + omega * ((sum - acc) / d - xi);
-    } else {
-      uH0[j] = 0.0;  // multigrid.hpp:278
-    }
-  }
+  dict_restrict_tail<R>(tile, n, rs, nH, fH, diagH, uH1, uH0, omega);
 }
 // (2) Jacobi sweep on level H + prolongation of its result into the finer level
 // (multigrid.hpp:300 on level l+1, then :294-296 on level l):
@@ -703,8 +746,7 @@ __global__ __launch_bounds__(256) void dict_jacobi_prolong_kernel(
     int n, const uint64_t* __restrict__ codes, const uint8_t* __restrict__ rtype,
     const uint64_t* __restrict__ rwords, const int32_t* __restrict__ doff,
     const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
-    double* out, double omega, int n_h, double* uh, int xcd_map) {
-  typedef double f64x2 __attribute__((ext_vector_type(2)));
+    double* out, double omega, int n_h, const double* uh_in, double* uh_out, int xcd_map) {
   __shared__ DictEntry tab[256];
   __shared__ uint64_t wtab[256 * WORDS];
   __shared__ double rs[256 * R];
@@ -723,31 +765,112 @@ __global__ __launch_bounds__(256) void dict_jacobi_prolong_kernel(
 #pragma unroll
   for (int r = 0; r < R; ++r) rs[threadIdx.x * R + r] = s.live[r] ? res[r] : 0.0;
   __syncthreads();
-  // this tile prolongs the coarse points q = 1 .. stride (q = 0 too in the first tile);
-  // j = n is the virtual point whose fine rows only receive the left neighbour / + 0.0
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int q = (int)threadIdx.x * R + r;
-    const int j = tile * stride + q;
-    if ((q == 0 && tile != 0) || q > stride || j > n) continue;
-    double t0 = 0.0, t1 = 0.0;
-    const double b = (j < n) ? rs[q] : 0.0;
-    if (j >= 1 && j - 1 < n) t0 += 0.5 * rs[q - 1];
-    if (j < n) {
-      t0 += 0.5 * b;
-      t1 += 1.0 * b;
+  dict_prolong_tail<R>(tile, n, rs, n_h, uh_in, uh_out);
+}
+
+// ---- two sweeps in one launch on small levels ----------------------------------------
+// Below ~300 K rows a launch costs more than its work (~5 us each), and the band is narrow
+// (half-bandwidth hb <= 64 rows).  A tile then computes its first Jacobi sweep on its rows
+// PLUS hb rows on either side (recomputed by the neighbouring tiles, <= 25 %) into an LDS
+// window, and the operation that follows reads its x from that window:
+//   down: sweep + (residual + restriction + first coarse sweep)   [dict_pair_down_kernel]
+//   up:   sweep + (sweep + prolongation into the finer level)     [dict_pair_up_kernel]
+// Same row arithmetic (dict_rows) and the same tails, so the V-cycle stays bit-identical.
+// R = 2 rows per lane, plain loads/stores.  w0 = tile start - hbw (hbw even >= hb).
+constexpr int PAIR_HB = 66;                       // largest half-window, in rows
+constexpr int PAIR_W = 512 + 2 * PAIR_HB;         // window capacity
+
+// first stage: Jacobi sweep of the window rows [w0, w0 + 512 + 2 hbw) from global `a` into
+// uw (0.0 for rows outside the matrix); rows of the tile are also stored to u_out if given
+template <int WORDS, int UN>
+__device__ __forceinline__ void dict_pair_stage1(int n, int w0, int hbw, const uint64_t* codes,
+                                                 const uint8_t* rtype, const DictEntry* tabJ,
+                                                 const uint64_t* wtab, const double* a,
+                                                 const double* f, double omega, double* uw,
+                                                 double* u_out) {
+  const int W = 512 + 2 * hbw;
+  for (int base = 0; base < W; base += 512) {  // 2 passes, the second one over the 2 hbw rows left
+    const int lw = base + (int)threadIdx.x * 2;  // index in the window
+    const int row0 = w0 + lw;
+    DictStream<WORDS, 2> s;
+    // rows before the matrix (first tile) or past the window: an empty stream, no loads.
+    // (row0 is even, so a pair is either entirely before row 0 or not at all.)
+    const bool inside = row0 >= 0 && lw < W;
+    dict_fetch<CSR_JACOBI, WORDS, false, 2>(s, inside ? row0 : 0, inside ? n : 0, codes, rtype, f, a, 0);
+    if (rtype) dict_expand<WORDS, 2>(s, wtab);
+    double res[2];
+    dict_rows<CSR_JACOBI, WORDS, UN, 2>(s, row0, tabJ, a, omega, 0, res);
+    if (lw < W) {
+      uw[lw] = s.live[0] ? res[0] : 0.0;
+      uw[lw + 1] = s.live[1] ? res[1] : 0.0;
     }
-    const int64_t i = 2 * (int64_t)j;
-    if (i + 1 < n_h) {
-      f64x2* up = reinterpret_cast<f64x2*>(uh + i);
-      f64x2 u = *up;
-      u.x = u.x + t0;
-      u.y = u.y + t1;
-      *up = u;
-    } else if (i < n_h) {
-      uh[i] = uh[i] + t0;
-    }
+    if (u_out && lw >= hbw && lw < hbw + 512) dict_store<WORDS, false, 2>(s, row0, res, u_out);
   }
+}
+template <int WORDS, int UN>
+__global__ __launch_bounds__(256) void dict_pair_down_kernel(
+    int n, const uint64_t* __restrict__ codes, const uint8_t* __restrict__ rtype,
+    const uint64_t* __restrict__ rwords, const int32_t* __restrict__ doff,
+    const double* __restrict__ dval, int ntab, const double* a, const double* __restrict__ f,
+    double* u_out, double* r_out, int nH, double* __restrict__ fH,
+    const double* __restrict__ diagH, double* __restrict__ uH1, double omega, int hbw,
+    int xcd_map) {
+  __shared__ DictEntry tabJ[256];
+  __shared__ DictEntry tabR[256];
+  __shared__ uint64_t wtab[256 * WORDS];
+  __shared__ double uw[PAIR_W];
+  __shared__ double rs[512];
+  const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
+  const int t0 = tile * 510, w0 = t0 - hbw;
+  dict_stage_table<CSR_JACOBI>(tabJ, doff, dval, ntab);
+  dict_stage_table<CSR_RESID>(tabR, doff, dval, ntab);
+  if (rtype) dict_stage_words<WORDS>(wtab, rwords);
+  __syncthreads();
+  dict_pair_stage1<WORDS, UN>(n, w0, hbw, codes, rtype, tabJ, wtab, a, f, omega, uw, u_out);
+  __syncthreads();
+  const int row0 = t0 + (int)threadIdx.x * 2;
+  DictStream<WORDS, 2> s;
+  dict_fetch<CSR_RESID, WORDS, false, 2>(s, row0, n, codes, rtype, f, a, 0);
+  if (rtype) dict_expand<WORDS, 2>(s, wtab);
+  double res[2];
+  dict_rows<CSR_RESID, WORDS, UN, 2>(s, row0 - w0, tabR, uw, omega, 0, res);  // x = the LDS window
+  if (r_out) dict_store<WORDS, false, 2>(s, row0, res, r_out);
+  rs[threadIdx.x * 2] = s.live[0] ? res[0] : 0.0;
+  rs[threadIdx.x * 2 + 1] = s.live[1] ? res[1] : 0.0;
+  __syncthreads();
+  dict_restrict_tail<2>(tile, n, rs, nH, fH, diagH, uH1, nullptr, omega);
+}
+template <int WORDS, int UN>
+__global__ __launch_bounds__(256) void dict_pair_up_kernel(
+    int n, const uint64_t* __restrict__ codes, const uint8_t* __restrict__ rtype,
+    const uint64_t* __restrict__ rwords, const int32_t* __restrict__ doff,
+    const double* __restrict__ dval, int ntab, const double* a, const double* __restrict__ f,
+    double* u_out, double omega, int hbw, int n_h, const double* uh_in, double* uh_out,
+    int xcd_map) {
+  __shared__ DictEntry tabJ[256];
+  __shared__ uint64_t wtab[256 * WORDS];
+  __shared__ double uw[PAIR_W];
+  __shared__ double rs[512];
+  const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
+  const int t0 = tile * 510, w0 = t0 - hbw;
+  dict_stage_table<CSR_JACOBI>(tabJ, doff, dval, ntab);
+  if (rtype) dict_stage_words<WORDS>(wtab, rwords);
+  __syncthreads();
+  dict_pair_stage1<WORDS, UN>(n, w0, hbw, codes, rtype, tabJ, wtab, a, f, omega, uw, nullptr);
+  __syncthreads();
+  const int row0 = t0 + (int)threadIdx.x * 2;
+  DictStream<WORDS, 2> s;
+  dict_fetch<CSR_RESID, WORDS, false, 2>(s, row0, n, codes, rtype, f, a, 0);  // types + f; xi from the window
+  s.xi[0] = uw[row0 - w0];
+  s.xi[1] = uw[row0 - w0 + 1];
+  if (rtype) dict_expand<WORDS, 2>(s, wtab);
+  double res[2];
+  dict_rows<CSR_JACOBI, WORDS, UN, 2>(s, row0 - w0, tabJ, uw, omega, 0, res);
+  dict_store<WORDS, false, 2>(s, row0, res, u_out);
+  rs[threadIdx.x * 2] = s.live[0] ? res[0] : 0.0;
+  rs[threadIdx.x * 2 + 1] = s.live[1] ? res[1] : 0.0;
+  __syncthreads();
+  dict_prolong_tail<2>(tile, n, rs, n_h, uh_in, uh_out);
 }
 
 // ---- one colour of the multicolour Gauss-Seidel sweep, dictionary-coded -----------------
@@ -875,10 +998,10 @@ hipError_t launch_dict_resid_restrict(int64_t n, const DictRef& D, const double*
 }
 hipError_t launch_dict_jacobi_prolong(int64_t n, const DictRef& D, const double* x,
                                       const double* f, double* out, double omega, int64_t n_h,
-                                      double* uh, hipStream_t st) {
+                                      const double* uh_in, double* uh_out, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  if (!dict_args_ok(n_h, D.words, D.wmax, D.ntab) || n > n_h || !uh ||
-      (reinterpret_cast<uintptr_t>(uh) & 15) != 0)
+  if (!dict_args_ok(n_h, D.words, D.wmax, D.ntab) || n > n_h || !uh_in || !uh_out ||
+      ((reinterpret_cast<uintptr_t>(uh_in) | reinterpret_cast<uintptr_t>(uh_out)) & 15) != 0)
     return hipErrorInvalidValue;
   const bool two = dict_two_rows(n, D, f, out);
   const int64_t stride = 256 * (two ? 2 : 1) - 2;
@@ -887,7 +1010,58 @@ hipError_t launch_dict_jacobi_prolong(int64_t n, const DictRef& D, const double*
     hipLaunchKernelGGL((dict_jacobi_prolong_kernel<decltype(W)::value, decltype(U)::value,
                                                    decltype(NTF)::value, decltype(RR)::value>),
                        dim3(tiles), dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff,
-                       D.dval, D.ntab, x, f, out, omega, (int)n_h, uh, dict_xcd_map(D));
+                       D.dval, D.ntab, x, f, out, omega, (int)n_h, uh_in, uh_out, dict_xcd_map(D));
+  });
+}
+// the two-sweep forms for small levels; see dict_pair_down_kernel / dict_pair_up_kernel
+bool dict_pair_ok(int64_t n, const DictRef& D, int hb, const void* a, const void* b, const void* c) {
+  return hb >= 0 && hb <= PAIR_HB - 1 && n >= 4096 && n <= 400000 && !D.nt &&
+         dict_args_ok(n, D.words, D.wmax, D.ntab) && g_dict_rows_per_lane == 2 &&
+         aligned16(a, b, c) && aligned16(D.rtype ? nullptr : D.codes, nullptr, nullptr) &&
+         (!D.rtype || (reinterpret_cast<uintptr_t>(D.rtype) & 1) == 0);
+}
+template <class F>
+static hipError_t dict_dispatch_wu(int words, int wmax, F&& go) {
+  using std::integral_constant;
+  if (words == 1) {
+    if (wmax <= 3) go(integral_constant<int, 1>{}, integral_constant<int, 3>{});
+    else if (wmax <= 5) go(integral_constant<int, 1>{}, integral_constant<int, 5>{});
+    else if (wmax <= 7) go(integral_constant<int, 1>{}, integral_constant<int, 7>{});
+    else go(integral_constant<int, 1>{}, integral_constant<int, 8>{});
+  } else {
+    if (wmax <= 9) go(integral_constant<int, 2>{}, integral_constant<int, 9>{});
+    else if (wmax <= 12) go(integral_constant<int, 2>{}, integral_constant<int, 12>{});
+    else go(integral_constant<int, 2>{}, integral_constant<int, 16>{});
+  }
+  return hipGetLastError();
+}
+hipError_t launch_dict_pair_down(int64_t n, const DictRef& D, int hb, const double* a,
+                                 const double* f, double* u_out, double* r_out, int64_t nH,
+                                 double* fH, const double* diagH, double* uH1, double omega,
+                                 hipStream_t st) {
+  if (!dict_pair_ok(n, D, hb, a, f, u_out) || !fH || !diagH || !uH1 || nH > n ||
+      (r_out && (reinterpret_cast<uintptr_t>(r_out) & 15)))
+    return hipErrorInvalidValue;
+  const int hbw = (hb + 1) & ~1;
+  const unsigned tiles = (unsigned)((n + 509) / 510);
+  return dict_dispatch_wu(D.words, D.wmax, [&](auto W, auto U) {
+    hipLaunchKernelGGL((dict_pair_down_kernel<decltype(W)::value, decltype(U)::value>), dim3(tiles),
+                       dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff, D.dval, D.ntab,
+                       a, f, u_out, r_out, (int)nH, fH, diagH, uH1, omega, hbw, dict_xcd_map(D));
+  });
+}
+hipError_t launch_dict_pair_up(int64_t n, const DictRef& D, int hb, const double* a,
+                               const double* f, double* u_out, double omega, int64_t n_h,
+                               const double* uh_in, double* uh_out, hipStream_t st) {
+  if (!dict_pair_ok(n, D, hb, a, f, u_out) || n > n_h || !uh_in || !uh_out ||
+      ((reinterpret_cast<uintptr_t>(uh_in) | reinterpret_cast<uintptr_t>(uh_out)) & 15) != 0)
+    return hipErrorInvalidValue;
+  const int hbw = (hb + 1) & ~1;
+  const unsigned tiles = (unsigned)((n + 509) / 510);
+  return dict_dispatch_wu(D.words, D.wmax, [&](auto W, auto U) {
+    hipLaunchKernelGGL((dict_pair_up_kernel<decltype(W)::value, decltype(U)::value>), dim3(tiles),
+                       dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff, D.dval, D.ntab,
+                       a, f, u_out, omega, hbw, (int)n_h, uh_in, uh_out, dict_xcd_map(D));
   });
 }
 void set_xcd_mapping(int on) { g_xcd_map = on ? 1 : 0; }
@@ -961,7 +1135,7 @@ hipError_t launch_linear_restrict(int64_t n_h, int64_t n_H, const double* r, dou
 }
 // Two fine rows (2j, 2j+1) per lane: 16-byte load/store of u, same arithmetic.
 __global__ __launch_bounds__(256) void linear_prolong_add2_kernel(
-    int64_t n_h, int64_t n_H, const double* __restrict__ uH, double* __restrict__ uh) {
+    int64_t n_h, int64_t n_H, const double* __restrict__ uH, const double* uh_in, double* uh) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t i = 2 * j;
   if (i >= n_h) return;
@@ -973,13 +1147,24 @@ __global__ __launch_bounds__(256) void linear_prolong_add2_kernel(
     t1 += 1.0 * b;
   }
   if (i + 1 < n_h) {
-    double2 u = *reinterpret_cast<const double2*>(uh + i);
+    double2 u = *reinterpret_cast<const double2*>(uh_in + i);
     u.x = u.x + t0;
     u.y = u.y + t1;
     *reinterpret_cast<double2*>(uh + i) = u;
   } else {
-    uh[i] = uh[i] + t0;
+    uh[i] = uh_in[i] + t0;
   }
+}
+// uh_out = uh_in + P uH (16-byte aligned vectors); uh_out == uh_in is the in-place form
+hipError_t launch_linear_prolong_to(int64_t n_h, int64_t n_H, const double* uH,
+                                    const double* uh_in, double* uh_out, hipStream_t st) {
+  if (n_h <= 0) return hipSuccess;
+  if (((reinterpret_cast<uintptr_t>(uh_in) | reinterpret_cast<uintptr_t>(uh_out)) & 15) != 0)
+    return hipErrorInvalidValue;
+  const int64_t nt = (n_h + 1) / 2;
+  hipLaunchKernelGGL(linear_prolong_add2_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0,
+                     st, n_h, n_H, uH, uh_in, uh_out);
+  return hipGetLastError();
 }
 hipError_t launch_linear_prolong_add(int64_t n_h, int64_t n_H, const double* uH,
                                      double* uh, hipStream_t st) {
@@ -987,7 +1172,7 @@ hipError_t launch_linear_prolong_add(int64_t n_h, int64_t n_H, const double* uH,
   if ((reinterpret_cast<uintptr_t>(uh) & 15) == 0) {
     const int64_t nt = (n_h + 1) / 2;
     hipLaunchKernelGGL(linear_prolong_add2_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256),
-                       0, st, n_h, n_H, uH, uh);
+                       0, st, n_h, n_H, uH, uh, uh);
   } else {
     hipLaunchKernelGGL(linear_prolong_add_kernel, dim3((unsigned)((n_h + 255) / 256)),
                        dim3(256), 0, st, n_h, n_H, uH, uh);

@@ -58,7 +58,21 @@ hipError_t launch_dict_resid_restrict(int64_t n, const DictRef& D, const double*
 // out = Jacobi sweep of x on this (coarse) level, then uh += P out on the finer level
 hipError_t launch_dict_jacobi_prolong(int64_t n, const DictRef& D, const double* x,
                                       const double* f, double* out, double omega, int64_t n_h,
-                                      double* uh, hipStream_t st);
+                                      const double* uh_in, double* uh_out, hipStream_t st);
+// Two sweeps in one launch on small levels (narrow band, hb = half-bandwidth in rows):
+//   down: u_out = Jacobi(a); r = f - A u_out (r_out optional); f_H = R r; uH1 = first coarse sweep
+//   up:   t = Jacobi(a) (not stored); u_out = Jacobi(t); uh_out = uh_in + P u_out
+bool dict_pair_ok(int64_t n, const DictRef& D, int hb, const void* a, const void* b, const void* c);
+hipError_t launch_dict_pair_down(int64_t n, const DictRef& D, int hb, const double* a,
+                                 const double* f, double* u_out, double* r_out, int64_t nH,
+                                 double* fH, const double* diagH, double* uH1, double omega,
+                                 hipStream_t st);
+hipError_t launch_dict_pair_up(int64_t n, const DictRef& D, int hb, const double* a,
+                               const double* f, double* u_out, double omega, int64_t n_h,
+                               const double* uh_in, double* uh_out, hipStream_t st);
+// uh_out = uh_in + P uH for the linear interpolation pair (16-byte aligned vectors)
+hipError_t launch_linear_prolong_to(int64_t n_h, int64_t n_H, const double* uH,
+                                    const double* uh_in, double* uh_out, hipStream_t st);
 hipError_t launch_dict(int mode, int64_t n, int words, int wmax, int nt, const uint64_t* codes,
                        const int32_t* doff, const double* dval, int ntab, const double* x,
                        const double* f, double* out, double omega, int64_t diag_shift,

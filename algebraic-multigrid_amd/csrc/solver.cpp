@@ -185,6 +185,7 @@ struct DevMat {
   bool dict = false;          // K-Dict (dictionary-coded rows)
   int dict_words = 0, dict_wmax = 0, dict_ntab = 0, dict_nt = 0;
   int64_t dict_shift = 0;
+  int dict_hb = 0;            // largest |column offset| of the table (half-bandwidth in rows)
   bool dict_typed = false;    // second level: one byte per row into a table of code words
   DevMem dcodes, doff, dval, drtype, drwords;
   DictRef dict_ref() const {
@@ -262,6 +263,8 @@ hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift
       D->dict_wmax = T.max_width;
       D->dict_ntab = (int)T.doff.size();
       D->dict_shift = diag_shift;
+      D->dict_hb = 0;
+      for (int32_t o : T.doff) D->dict_hb = std::max<int>(D->dict_hb, o < 0 ? -o : o);
       // one sweep streams codes + f + out and gathers x: non-temporal stream when
       // that is well beyond the 256 MiB Infinity Cache
       D->dict_typed = g_row_types != 0 && !T.rtype.empty();
@@ -498,9 +501,24 @@ bool fuses_jacobi_prolong(const amg_hip_solver* s, int l) {
          s->opt.stencil_transfers && AC.dict && AC.dict_shift == 0;
 }
 
+// two sweeps in one launch (kernels.hip: dict_pair_*_kernel): small, narrow-band,
+// symmetric levels of the 2+2 true-Jacobi cycle
+bool pair_level_ok(const amg_hip_solver* s, int l) {
+  if (l < 1 || l + 1 >= (int)s->lv.size()) return false;
+  const Level& L = s->lv[l];
+  const DevMat& A = L.A_rows;
+  return jacobi_fuses_zero(s) && s->opt.smoother_iters == 2 && L.symmetric && A.dict &&
+         A.dict_shift == 0 && fuses_resid_restrict(s, l) &&
+         dict_pair_ok(L.n, A.dict_ref(), A.dict_hb, L.u.p, L.f.p, L.tmp.p);
+}
+bool pair_up_ok(const amg_hip_solver* s, int l) {  // its second sweep prolongs into level l-1
+  return pair_level_ok(s, l) && fuses_jacobi_prolong(s, l - 1);
+}
+
 // phase 3: the first sweep was already done by the fused kernel of the finer level
 // (result in tmp).  prolong_into >= 0: the last sweep also adds P u_l to that level's u.
-amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolong_into = -1) {
+amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolong_into = -1,
+                              double* prolong_out = nullptr) {
   Level& L = s->lv[l];
   hipStream_t st = s->stream;
   const int iters = s->opt.smoother_iters;
@@ -545,7 +563,8 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
         if (prolong_into >= 0 && it == iters - 1) {
           Level& F = s->lv[prolong_into];
           HIP_TRY(launch_dict_jacobi_prolong(A.n_rows, A.dict_ref(), a, L.f.as<double>(), b,
-                                             s->opt.omega, F.n, F.u.as<double>(), st));
+                                             s->opt.omega, F.n, F.u.as<double>(),
+                                             prolong_out ? prolong_out : F.u.as<double>(), st));
         } else {
           HIP_TRY(launch_mat(CSR_JACOBI, A, a, L.f.as<double>(), b, s->opt.omega, st));
         }
@@ -603,6 +622,17 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
     // u with the direct solve of the level's rhs (multigrid.hpp:268-274, :287-288): unless
     // the residual is to be kept, neither has an observable effect.
     if (l == nl - 1 && nl > 1 && !s->opt.keep_residual) break;
+    if (first_sweep_done && pair_level_ok(s, l)) {  // second pre-sweep + residual + restriction
+      Level& L = s->lv[l];
+      Level& C = s->lv[l + 1];
+      const DevMat& A = L.A_rows;
+      HIP_TRY(launch_dict_pair_down(A.n_rows, A.dict_ref(), A.dict_hb, L.tmp.as<double>(),
+                                    L.f.as<double>(), L.u.as<double>(),
+                                    s->opt.keep_residual ? L.r.as<double>() : nullptr, C.n,
+                                    C.f.as<double>(), C.diag.as<double>(), C.tmp.as<double>(),
+                                    s->opt.omega, st));
+      continue;  // first_sweep_done stays true for level l+1
+    }
     amg_hip_status r =
         enqueue_smooth(s, l, first_sweep_done ? 3 : (l >= 1 && zero_known) ? 1 : 0);  // :268
     if (r != AMG_HIP_OK) return r;
@@ -652,20 +682,29 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
                                 C.tmp.as<double>(), C.u.as<double>(), st));
     }
   }
+  // where the prolongation INTO level l lands: a level whose two post-sweeps run as one
+  // launch reads u + P u_{l+1} from tmp (its second sweep then writes u; no in-place race
+  // between the tiles), every other level takes it in place
+  auto up_target = [&](int l) -> double* {
+    return pair_up_ok(s, l) ? s->lv[l].tmp.as<double>() : s->lv[l].u.as<double>();
+  };
   for (int l = nl - 2; l >= 0; --l) {                              // :291
     Level& L = s->lv[l];
     Level& C = s->lv[l + 1];
     // the last sweep of this level also prolongs into level l-1 when that fuses
     const int into = (l >= 1 && fuses_jacobi_prolong(s, l - 1)) ? l - 1 : -1;
     if (jacobi_fuses_prolong(s, l)) {                              // :294-296 inside :300
-      amg_hip_status r = enqueue_smooth(s, l, 2, into);
+      amg_hip_status r = enqueue_smooth(s, l, 2, into, into >= 0 ? up_target(into) : nullptr);
       if (r != AMG_HIP_OK) return r;
       continue;
     }
     if (fuses_jacobi_prolong(s, l)) {
       // :294-296 was done by the last sweep of level l+1
     } else if (L.linear && s->opt.stencil_transfers) {             // :294-296
-      HIP_TRY(launch_linear_prolong_add(L.n, C.n, C.u.as<double>(), L.u.as<double>(), st));
+      if (up_target(l) != L.u.as<double>())
+        HIP_TRY(launch_linear_prolong_to(L.n, C.n, C.u.as<double>(), L.u.as<double>(), up_target(l), st));
+      else
+        HIP_TRY(launch_linear_prolong_add(L.n, C.n, C.u.as<double>(), L.u.as<double>(), st));
     } else {
       const DevCsr& P = L.P_rows;
       HIP_TRY(launch_csr(CSR_SPMV, P.n_rows, P.nnz, P.max_block_nnz, P.max_row_nnz,
@@ -673,7 +712,15 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
                          L.tmp.as<double>(), 1.0, 0, st));
       HIP_TRY(launch_add_inplace(L.n, L.tmp.as<double>(), L.u.as<double>(), st));
     }
-    amg_hip_status r = enqueue_smooth(s, l, 0, into);              // :300
+    if (pair_up_ok(s, l)) {                                        // :300, both sweeps
+      Level& F = s->lv[l - 1];
+      const DevMat& A = L.A_cols();
+      HIP_TRY(launch_dict_pair_up(A.n_rows, A.dict_ref(), A.dict_hb, L.tmp.as<double>(),
+                                  L.f.as<double>(), L.u.as<double>(), s->opt.omega, F.n,
+                                  F.u.as<double>(), up_target(l - 1), st));
+      continue;
+    }
+    amg_hip_status r = enqueue_smooth(s, l, 0, into, into >= 0 ? up_target(into) : nullptr);  // :300
     if (r != AMG_HIP_OK) return r;
   }
   return AMG_HIP_OK;
