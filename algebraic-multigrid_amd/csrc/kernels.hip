@@ -1015,7 +1015,7 @@ hipError_t launch_dict_jacobi_prolong(int64_t n, const DictRef& D, const double*
 }
 // the two-sweep forms for small levels; see dict_pair_down_kernel / dict_pair_up_kernel
 bool dict_pair_ok(int64_t n, const DictRef& D, int hb, const void* a, const void* b, const void* c) {
-  return hb >= 0 && hb <= PAIR_HB - 1 && n >= 4096 && n <= 400000 && !D.nt &&
+  return hb >= 0 && hb <= PAIR_HB - 1 && n >= 256 && n <= 400000 && !D.nt &&
          dict_args_ok(n, D.words, D.wmax, D.ntab) && g_dict_rows_per_lane == 2 &&
          aligned16(a, b, c) && aligned16(D.rtype ? nullptr : D.codes, nullptr, nullptr) &&
          (!D.rtype || (reinterpret_cast<uintptr_t>(D.rtype) & 1) == 0);
