@@ -112,7 +112,7 @@ def run_single(args):
     # what the format has to move per sweep: matrix stream + f + x + out (8 B each per row)
     format_bytes = mat_bytes + 24 * sizes[0]
     kernel = {"dict": ("dict_kernel<CSR_JACOBI, 1 code word, 5 entries, nt, 2 rows/lane> (level-0 Jacobi sweep, "
-                       "dictionary-coded rows, one byte per row)", "r01g_pmc_traffic", "dict_kernel<1, 1, 5, true, 2>@L0"),
+                       "dictionary-coded rows, one byte per row)", "r01h_pmc_traffic", "dict_kernel<1, 1, 5, true, 2>@L0"),
               "sell": ("sell_kernel<CSR_JACOBI, idx16, nt> (level-0 Jacobi sweep, SELL-64 panels)",
                        "r01c_pmc_traffic", "sell_kernel<1, true, true>@16777216"),
               "csr": ("csr_stage_kernel<CSR_JACOBI> (level-0 Jacobi sweep, LDS-staged CSR)", None, None)}[lay_name]
