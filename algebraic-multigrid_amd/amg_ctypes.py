@@ -37,7 +37,8 @@ class Options(C.Structure):
                 ("host_only", C.c_int32), ("keep_structural_zeros", C.c_int32),
                 ("no_fusion", C.c_int32), ("fuse_prolong", C.c_int32),
                 ("fast_coarse_solve", C.c_int32), ("host_galerkin", C.c_int32),
-                ("keep_residual", C.c_int32),
+                ("keep_residual", C.c_int32), ("exact_coarse_solve", C.c_int32),
+                ("exact_gs", C.c_int32),
                 ("stream", C.c_void_p)]
 
 
@@ -99,6 +100,8 @@ _SIGS = {
     "amg_hip_copy_vec_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "amg_hip_zero_vec": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "amg_hip_coarse_halfbw": (C.c_int64, [C.c_void_p]),
+    "amg_hip_coarse_solve_kind": (C.c_int32, [C.c_void_p]),
+    "amg_hip_fine_sweep_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _i32p]),
     "amg_hip_level_layout": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "amg_hip_get_colors": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p]),
     "amg_hip_level_op": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
@@ -270,7 +273,8 @@ class Multigrid:
                  n_iters=100, device=-1, use_graph=True, stencil_transfers=True,
                  transfers=None, layout=None, host_only=False, keep_structural_zeros=False,
                  no_fusion=False, fuse_prolong=False, stream=None, fast_coarse_solve=False,
-                 host_galerkin=False, keep_residual=False):
+                 host_galerkin=False, keep_residual=False, exact_coarse_solve=False,
+                 exact_gs=False):
         # multigrid.hpp:165-178 (same checks, same order)
         if compute_error_every_n_iters > n_iters:
             raise ValueError("`compute_error_every_n_iters` must be leq to `n_iters`, got "
@@ -296,6 +300,8 @@ class Multigrid:
         o.fast_coarse_solve = int(fast_coarse_solve)
         o.host_galerkin = int(host_galerkin)
         o.keep_residual = int(keep_residual)
+        o.exact_coarse_solve = int(exact_coarse_solve)
+        o.exact_gs = int(exact_gs)
         if stream:
             o.stream = C.c_void_p(stream)
         h = C.c_void_p()
@@ -415,11 +421,19 @@ class Multigrid:
         return a.value, b.value
 
     def profile_fine_sweep(self, n_launches):
-        """(avg_ms, min_ms) of the level-0 Jacobi sweep kernel, HIP events on
-        the solver's stream."""
+        """(avg_ms, min_ms, sweeps per launch, kernel name) of the level-0 Jacobi sweep
+        kernel, HIP events on the solver's stream."""
         a, b = C.c_double(0), C.c_double(0)
         _chk(lib().amg_hip_profile_fine_sweep(self._h, n_launches, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        name = C.create_string_buffer(256)
+        k = C.c_int32(0)
+        _chk(lib().amg_hip_fine_sweep_info(self._h, name, 256, C.byref(k)))
+        return a.value, b.value, k.value, name.value.decode()
+
+    def coarse_solve_kind(self):
+        return {0: "band (one wave, sequential, bit-exact)", 1: "spike (partitioned, parallel)",
+                2: "band-wide (blocked sequential, any half-bandwidth, bit-exact)"}[
+                    int(lib().amg_hip_coarse_solve_kind(self._h))]
 
     def level_op(self, level, op):
         """op: 0 smooth (built-in), 1 residual, 2 zero+restrict, 3 prolong+add, 4 coarse solve."""

@@ -536,6 +536,46 @@ std::string band_schedule(const BandFactor& F, BandSchedule* S) {
   return "";
 }
 
+std::string band_wide_schedule(const BandFactor& F, size_t max_bytes, BandWide* S) {
+  const int64_t n = F.n, w = F.w;
+  if (w + 64 > 8192)
+    return "coarsest operator has half-bandwidth " + std::to_string(w) +
+           " > 8128 (device band solve limit); use more levels";
+  const int64_t nb = (n + 63) / 64, stride = (w + 64) * 64;
+  if ((size_t)nb * (size_t)stride * sizeof(double) * 2 > max_bytes)
+    return "coarsest operator: band solve panels of " + std::to_string(nb) + " x " +
+           std::to_string(stride) + " doubles exceed the limit; use more levels";
+  S->n = n;
+  S->w = w;
+  S->d = F.d;
+  S->sched_f.assign((size_t)(nb * stride), 0.0);
+  S->sched_b.assign((size_t)(nb * stride), 0.0);
+  auto L = [&](int64_t i, int64_t j) -> double {  // L[i, j], i > j, inside the band
+    return F.lcol[j * w + (i - j - 1)];
+  };
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t r0 = b * 64;
+    double* pf = S->sched_f.data() + b * stride;
+    double* pb = S->sched_b.data() + b * stride;
+    for (int64_t l = 0; l < 64 && r0 + l < n; ++l) {
+      const int64_t i = r0 + l;          // forward: row i; mirrored: row n-1-i
+      for (int64_t t = 0; t < w; ++t) {
+        const int64_t k = i - w + t;
+        if (k < 0 || k >= r0) continue;
+        pf[t * 64 + l] = L(i, k);
+        pb[t * 64 + l] = L(n - 1 - k, n - 1 - i);
+      }
+      for (int64_t s = 0; s < l; ++s) {
+        const int64_t k = r0 + s;
+        if (i - k > w) continue;
+        pf[(w + s) * 64 + l] = L(i, k);
+        pb[(w + s) * 64 + l] = L(n - 1 - k, n - 1 - i);
+      }
+    }
+  }
+  return "";
+}
+
 std::string spike_factor(const BandFactor& F, SpikeFactor* S) {
   const int64_t n = F.n;
   const int w = (int)F.w;

@@ -112,6 +112,19 @@ struct BandSchedule {
 // fails when w > 63
 std::string band_schedule(const BandFactor& F, BandSchedule* out);
 
+// Device layout for the general-bandwidth kernel (K-BandWide, w > 63): rows in blocks of
+// 64.  Per block b a panel of (w + 64) x 64 doubles, [t][lane]:
+//   t < w : L[i, i-w+t] for row i = 64 b + lane when that column lies in an EARLIER block
+//   t >= w: L[i, 64 b + (t-w)] -- the block's own strictly lower triangle
+// (zero elsewhere).  sched_b is the same thing for the mirrored system L'[i',k'] =
+// L[n-1-k', n-1-i'], i.e. the L^T solve walked from the last row.
+struct BandWide {
+  int64_t n = 0, w = 0;
+  std::vector<double> sched_f, sched_b, d;
+};
+// fails when the panels would need more than max_bytes or the LDS ring (w + 64 > 8192)
+std::string band_wide_schedule(const BandFactor& F, size_t max_bytes, BandWide* out);
+
 // Partitioned ("spike") form of the same factor for the parallel coarse solve:
 // the n rows are cut into P partitions of c rows (c a multiple of 64, c >= w).
 // Every partition solves its own triangular system with the one-wave substitution

@@ -40,6 +40,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
 #include <type_traits>
 #include <utility>
 
@@ -1078,6 +1079,14 @@ static hipError_t launch_dict_mode(int64_t n, const DictRef& D, const double* x,
                        D.dval, D.ntab, x, f, out, omega, (int)dshift, dict_xcd_map(D));
   });
 }
+// the name rocprofv3 prints for the launch launch_dict(mode, ...) makes
+void dict_kernel_name(int mode, int64_t n, const DictRef& D, const void* f, const void* out,
+                      char* buf, size_t cap) {
+  const int u = D.words == 1 ? (D.wmax <= 3 ? 3 : D.wmax <= 5 ? 5 : D.wmax <= 7 ? 7 : 8)
+                             : (D.wmax <= 9 ? 9 : D.wmax <= 12 ? 12 : 16);
+  std::snprintf(buf, cap, "dict_kernel<%d, %d, %d, %s, %d>", mode, D.words, u,
+                D.nt ? "true" : "false", dict_two_rows(n, D, f, out) ? 2 : 1);
+}
 hipError_t launch_dict(int mode, int64_t n, const DictRef& D, const double* x, const double* f,
                        double* out, double omega, int64_t diag_shift, hipStream_t st) {
   if (n <= 0) return hipSuccess;
@@ -1620,6 +1629,81 @@ __global__ __launch_bounds__(64) void band_solve_kernel(
   band_pass<M, false>(n, lane, sched_b, y, x);          // L^T x = z
 }
 
+// ------------------------------------------------------------- K-BandWide -----
+// The same LDL^T substitution for ANY half-bandwidth w (the reference's SimplicialLDLT
+// factors whatever coarsest matrix it is given, multigrid.hpp:240-243): rows in blocks of
+// 64, one wave, lane l owns row r0 + l of the current block.
+//   phase 1: the terms that come from earlier blocks, k = i-w .. r0-1 in ascending k --
+//            a private loop per lane over the block's [t][lane] operand panel (coalesced
+//            512-B loads), y_k from an LDS ring that holds the last w + 64 results;
+//   phase 2: the 64 x 64 triangle of the block itself, step s broadcasts the finished
+//            y_{r0+s} with v_readlane (ascending k again).
+// Every row therefore subtracts its products in exactly the order of the row-oriented
+// substitution (oracle band_solve), so the result has the same bits.  The backward pass
+// runs the same code on the mirrored system (row n-1-i, host_setup.cpp: band_wide_schedule).
+template <bool FWD>
+__device__ __forceinline__ void band_wide_pass(int64_t n, int w, int ringmask, double* ring,
+                                               const double* __restrict__ sched,
+                                               const double* rhs, double* out) {
+  const int lane = threadIdx.x;
+  const int64_t nb = (n + 63) / 64;
+  const int64_t stride = (int64_t)(w + 64) * 64;
+  for (int k = lane; k <= ringmask; k += 64) ring[k] = 0.0;
+  __syncthreads();
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t r0 = b * 64, i = r0 + lane;
+    const bool live = i < n;
+    double acc = live ? rhs[FWD ? i : n - 1 - i] : 0.0;
+    const double* __restrict__ Lp = sched + b * stride + lane;
+    const int64_t tl = (int64_t)w - i;
+    const int tlo = tl > 0 ? (int)tl : 0, thi = w - lane;  // k >= 0 and k < r0
+    if (b > 0) {
+#pragma unroll 4
+      for (int t = 0; t < w; ++t) {
+        const double v = Lp[(int64_t)t * 64];
+        const double yk = ring[(int)((i - w + t) & ringmask)];
+        const double p = v * yk;
+        acc = (t >= tlo && t < thi) ? acc - p : acc;
+      }
+    }
+    const double* __restrict__ Ld = Lp + (int64_t)w * 64;
+#pragma unroll 16
+    for (int s = 0; s < 64; ++s) {
+      const double vk = readlane_f64(acc, s);
+      const double p = Ld[s * 64] * vk;
+      acc = (lane > s) ? acc - p : acc;
+    }
+    if (live) {
+      ring[(int)(i & ringmask)] = acc;
+      out[FWD ? i : n - 1 - i] = acc;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(64) void band_wide_kernel(
+    int64_t n, int w, int ringmask, const double* __restrict__ sched_f,
+    const double* __restrict__ sched_b, const double* __restrict__ dg, const double* f, double* y,
+    double* x) {
+  extern __shared__ double ring[];
+  band_wide_pass<true>(n, w, ringmask, ring, sched_f, f, y);   // L y = f
+  __threadfence_block();
+  for (int64_t i = threadIdx.x; i < n; i += 64) y[i] = y[i] / dg[i];  // z = y / D
+  __threadfence_block();
+  __syncthreads();
+  band_wide_pass<false>(n, w, ringmask, ring, sched_b, y, x);  // L^T x = z
+}
+hipError_t launch_band_wide(int64_t n, int64_t w, const double* sched_f, const double* sched_b,
+                            const double* dg, const double* f, double* y, double* x,
+                            hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  int64_t R = 128;
+  while (R < w + 64) R *= 2;
+  if (R * 8 > 65536 || w < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(band_wide_kernel, dim3(1), dim3(64), (size_t)R * 8, st, n, (int)w, (int)(R - 1),
+                     sched_f, sched_b, dg, f, y, x);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- K-Spike -----
 // Parallel form of the same LDL^T solve (host_setup.cpp: spike_factor): P partitions
 // of c rows.  (A) every partition runs the one-wave substitution above on its own
@@ -1841,15 +1925,32 @@ __global__ __launch_bounds__(256) void scan_block_sums_kernel(int64_t n, const i
   }
   if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
 }
-__global__ void scan_block_offsets_kernel(int64_t nb, int64_t* bsum, int64_t* total) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int64_t run = 0;
-  for (int64_t b = 0; b < nb; ++b) {
+// exclusive scan of the <= 2^21 block sums by ONE workgroup: thread t owns a contiguous
+// run of ceil(nb / 1024) sums, the 1024 run totals are scanned in LDS
+__global__ __launch_bounds__(1024) void scan_block_offsets_kernel(int64_t nb, int64_t* bsum,
+                                                                  int64_t* total) {
+  __shared__ int64_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (nb + 1023) / 1024;
+  const int64_t b0 = (int64_t)t * per;
+  const int64_t b1 = b0 + per < nb ? b0 + per : nb;
+  int64_t s = 0;
+  for (int64_t b = b0; b < b1; ++b) s += bsum[b];
+  part[t] = s;
+  __syncthreads();
+  for (int st = 1; st < 1024; st <<= 1) {
+    const int64_t add = t >= st ? part[t - st] : 0;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  int64_t run = part[t] - s;
+  for (int64_t b = b0; b < b1; ++b) {
     const int64_t v = bsum[b];
     bsum[b] = run;
     run += v;
   }
-  *total = run;
+  if (t == 1023) *total = part[1023];
 }
 __global__ __launch_bounds__(256) void scan_finish_kernel(int64_t n, const int32_t* __restrict__ in,
                                                           const int64_t* __restrict__ bsum,
@@ -1885,7 +1986,7 @@ hipError_t launch_exclusive_scan(int64_t n, const int32_t* counts, int32_t* offs
   if (n <= 0) return hipErrorInvalidValue;
   const int64_t nb = (n + 1023) / 1024;
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, counts, bsum);
-  hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(1), 0, st, nb, bsum, total);
+  hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(1024), 0, st, nb, bsum, total);
   hipLaunchKernelGGL(scan_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, counts, bsum,
                      offsets);
   return hipGetLastError();

@@ -1,6 +1,7 @@
 // Launchers of the gfx950 kernels (kernels.hip).  Device pointers only.
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace amg_hip {
@@ -43,6 +44,8 @@ void set_xcd_mapping(int on);  // contiguous run of tiles per XCD (default on)
 void set_dict_rows_per_lane(int r);  // 1 or 2 (default), tuning / test switch
 hipError_t launch_dict(int mode, int64_t n, const DictRef& D, const double* x, const double* f,
                        double* out, double omega, int64_t diag_shift, hipStream_t st);
+void dict_kernel_name(int mode, int64_t n, const DictRef& D, const void* f, const void* out,
+                      char* buf, size_t cap);
 // one colour of the multicolour GS sweep on a dictionary-coded colour-permuted copy
 hipError_t launch_dict_gs_color(int64_t p0, int64_t count, int words, int wmax,
                                 const uint64_t* codes, const int32_t* rowid, const int32_t* doff,
@@ -148,6 +151,13 @@ hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, 
 hipError_t launch_band_solve(int64_t n, int m, const double* sched_f, const double* sched_b,
                              const double* dg, const double* f, double* y, double* x,
                              hipStream_t st);
+
+// Any half-bandwidth (K-BandWide): rows in blocks of 64; sched_f/sched_b hold per block a
+// [w][64] panel of the operands that reach into earlier blocks followed by the block's own
+// [64][64] triangle (host_setup: band_wide_schedule).  w + 64 <= 8192 (LDS ring).
+hipError_t launch_band_wide(int64_t n, int64_t w, const double* sched_f, const double* sched_b,
+                            const double* dg, const double* f, double* y, double* x,
+                            hipStream_t st);
 
 // Partitioned coarse solve (K-Spike); arrays as in host_setup.hpp: SpikeFactor.
 struct SpikeArgs {

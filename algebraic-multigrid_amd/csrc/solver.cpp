@@ -368,6 +368,77 @@ hipError_t upload_spike(const SpikeFactor& S, SpikeOnDev* D) {
   return hipSuccess;
 }
 
+// The factored coarsest operator on the device in one of three forms:
+//   BAND  one-wave substitution, half-bandwidth <= 63, bit-exact against the oracle
+//   SPIKE partitioned (parallel) form of the same factor, <= 63, agrees to ~1e-14
+//   WIDE  blocked one-wave substitution for any half-bandwidth, bit-exact
+enum CoarseKind { COARSE_BAND = 0, COARSE_SPIKE = 1, COARSE_WIDE = 2 };
+struct CoarseOnDev {
+  int kind = COARSE_BAND;
+  int64_t n = 0, w = 0;
+  int m = 0;
+  DevMem sf, sb, d;                  // BAND / WIDE schedules
+  std::unique_ptr<SpikeOnDev> spike;
+};
+// serial substitution costs ~44 ns per row and pass; from this size on the partitioned
+// solve is the default (opt.exact_coarse_solve keeps the bit-exact one)
+constexpr int64_t COARSE_SPIKE_MIN_ROWS = 4096;
+// want_fast: 1 = partitioned whenever it applies, 0 = by size, -1 = never
+amg_hip_status upload_coarse(const Sparse& A, int want_fast, CoarseOnDev* C) {
+  BandFactor F;
+  std::string e = band_factor(A, (size_t)8 << 30, &F);
+  if (!e.empty()) return fail(AMG_HIP_EINVAL, e);
+  C->n = F.n;
+  C->w = F.w;
+  if (F.w > 63) {
+    BandWide W;
+    e = band_wide_schedule(F, (size_t)16 << 30, &W);
+    if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
+    C->kind = COARSE_WIDE;
+    HIP_TRY(upload(C->sf, W.sched_f.data(), W.sched_f.size()));
+    HIP_TRY(upload(C->sb, W.sched_b.data(), W.sched_b.size()));
+    HIP_TRY(upload(C->d, W.d.data(), W.d.size()));
+    return AMG_HIP_OK;
+  }
+  if (want_fast > 0 || (want_fast == 0 && F.n >= COARSE_SPIKE_MIN_ROWS)) {
+    SpikeFactor SF;
+    e = spike_factor(F, &SF);
+    if (e.empty()) {
+      C->kind = COARSE_SPIKE;
+      C->spike.reset(new SpikeOnDev);
+      HIP_TRY(upload_spike(SF, C->spike.get()));
+      return AMG_HIP_OK;
+    }
+  }
+  BandSchedule S;
+  e = band_schedule(F, &S);
+  if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
+  C->kind = COARSE_BAND;
+  C->m = S.m;
+  HIP_TRY(upload(C->sf, S.sched_f.data(), S.sched_f.size()));
+  HIP_TRY(upload(C->sb, S.sched_b.data(), S.sched_b.size()));
+  HIP_TRY(upload(C->d, S.d.data(), S.d.size()));
+  return AMG_HIP_OK;
+}
+// x = A^-1 f; y: scratch of n doubles (BAND / WIDE)
+hipError_t launch_coarse(const CoarseOnDev& C, const double* f, double* y, double* x,
+                         hipStream_t st) {
+  switch (C.kind) {
+    case COARSE_SPIKE: {
+      SpikeArgs a = C.spike->a;
+      a.f = f;
+      a.x = x;
+      return launch_spike_solve(a, st);
+    }
+    case COARSE_WIDE:
+      return launch_band_wide(C.n, C.w, C.sf.as<double>(), C.sb.as<double>(), C.d.as<double>(), f,
+                              y, x, st);
+    default:
+      return launch_band_solve(C.n, C.m, C.sf.as<double>(), C.sb.as<double>(), C.d.as<double>(),
+                               f, y, x, st);
+  }
+}
+
 struct LexOnDev {
   LexDev d;
   DevMem row, depth, win_depth, col, val, src;
@@ -441,12 +512,7 @@ struct amg_hip_solver {
   hipStream_t stream = nullptr;
   bool own_stream = true;
   std::vector<Level> lv;
-  // coarsest level factor
-  int64_t band_n = 0, band_w = 0;
-  int band_m = 0;
-  DevMem band_f, band_b, band_d;
-  // partitioned (parallel) form of the same factor, opt.fast_coarse_solve
-  std::unique_ptr<SpikeOnDev> spike;
+  CoarseOnDev coarse;  // coarsest level factor
   DevMem scratch;   // 1024 doubles + 1 result
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -671,16 +737,7 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
   }
   {                                                                // :287-288
     Level& C = s->lv[nl - 1];
-    if (s->spike) {
-      SpikeArgs a = s->spike->a;
-      a.f = C.f.as<double>();
-      a.x = C.u.as<double>();
-      HIP_TRY(launch_spike_solve(a, st));
-    } else {
-      HIP_TRY(launch_band_solve(s->band_n, s->band_m, s->band_f.as<double>(),
-                                s->band_b.as<double>(), s->band_d.as<double>(), C.f.as<double>(),
-                                C.tmp.as<double>(), C.u.as<double>(), st));
-    }
+    HIP_TRY(launch_coarse(s->coarse, C.f.as<double>(), C.tmp.as<double>(), C.u.as<double>(), st));
   }
   // where the prolongation INTO level l lands: a level whose two post-sweeps run as one
   // launch reads u + P u_{l+1} from tmp (its second sweep then writes u; no in-place race
@@ -986,26 +1043,9 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
   HIP_TRY(hipMemcpy(s->lv[0].r.p, b, sizeof(double) * n, hipMemcpyHostToDevice));  // b - A*0
   // ---- coarsest factor (multigrid.hpp:240-243) ----
   {
-    BandFactor F;
-    std::string e = band_factor(s->lv[n_levels - 1].A_csc, (size_t)8 << 30, &F);
-    if (!e.empty()) return fail(AMG_HIP_EINVAL, e);
-    BandSchedule S;
-    e = band_schedule(F, &S);
-    if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
-    if (s->opt.fast_coarse_solve) {
-      SpikeFactor SF;
-      e = spike_factor(F, &SF);
-      if (e.empty()) {
-        s->spike.reset(new SpikeOnDev);
-        HIP_TRY(upload_spike(SF, s->spike.get()));
-      }
-    }
-    s->band_n = F.n;
-    s->band_w = F.w;
-    s->band_m = S.m;
-    HIP_TRY(upload(s->band_f, S.sched_f.data(), S.sched_f.size()));
-    HIP_TRY(upload(s->band_b, S.sched_b.data(), S.sched_b.size()));
-    HIP_TRY(upload(s->band_d, S.d.data(), S.d.size()));
+    const int want = s->opt.fast_coarse_solve ? 1 : (s->opt.exact_coarse_solve ? -1 : 0);
+    amg_hip_status r = upload_coarse(s->lv[n_levels - 1].A_csc, want, &s->coarse);
+    if (r != AMG_HIP_OK) return r;
   }
   timer.lap(T_BAND);
   HIP_TRY(s->scratch.alloc(sizeof(double) * 1100));
@@ -1185,16 +1225,7 @@ amg_hip_status amg_hip_level_op(amg_hip_solver* s, int32_t level, int32_t op) {
     }
     case 4:
       if (level != nl - 1) return fail(AMG_HIP_EINVAL, "the direct solve belongs to the coarsest level");
-      if (s->spike) {
-        SpikeArgs a = s->spike->a;
-        a.f = L.f.as<double>();
-        a.x = L.u.as<double>();
-        HIP_TRY(launch_spike_solve(a, st));
-        return AMG_HIP_OK;
-      }
-      HIP_TRY(launch_band_solve(s->band_n, s->band_m, s->band_f.as<double>(), s->band_b.as<double>(),
-                                s->band_d.as<double>(), L.f.as<double>(), L.tmp.as<double>(),
-                                L.u.as<double>(), st));
+      HIP_TRY(launch_coarse(s->coarse, L.f.as<double>(), L.tmp.as<double>(), L.u.as<double>(), st));
       return AMG_HIP_OK;
   }
   return fail(AMG_HIP_EINVAL, "unknown level operation");
@@ -1300,7 +1331,8 @@ amg_hip_status amg_hip_set_vec(amg_hip_solver* s, int32_t level, int32_t which,
   HIP_TRY(hipMemcpy(m->p, in, sizeof(double) * s->lv[level].n, hipMemcpyHostToDevice));
   return AMG_HIP_OK;
 }
-int64_t amg_hip_coarse_halfbw(const amg_hip_solver* s) { return s ? s->band_w : -1; }
+int64_t amg_hip_coarse_halfbw(const amg_hip_solver* s) { return s ? s->coarse.w : -1; }
+int32_t amg_hip_coarse_solve_kind(const amg_hip_solver* s) { return s ? s->coarse.kind : -1; }
 
 static void layout_of(const DevMat& A, int32_t* layout, int64_t* matrix_stream_bytes) {
   int32_t lay;
@@ -1376,6 +1408,24 @@ amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
   for (auto& e : ev) (void)hipEventDestroy(e);
   if (avg_ms) *avg_ms = sum / n_launches;
   if (min_ms) *min_ms = mn;
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_fine_sweep_info(const amg_hip_solver* s, char* name, int32_t name_cap,
+                                       int32_t* sweeps_per_launch) {
+  if (!s || !name || name_cap < 32) return fail(AMG_HIP_EINVAL, "bad argument");
+  if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "host_only solver has no device matrices");
+  const Level& L = s->lv[0];
+  const DevMat& A = L.A_cols();
+  if (A.dict) {
+    dict_kernel_name(CSR_JACOBI, A.n_rows, A.dict_ref(), L.f.p, L.tmp.p, name, (size_t)name_cap);
+  } else if (A.sell) {
+    std::snprintf(name, (size_t)name_cap, "sell_kernel<1, %s, %s>", (A.idx16 & 1) ? "true" : "false",
+                  (A.idx16 & 2) ? "true" : "false");
+  } else {
+    std::snprintf(name, (size_t)name_cap, "csr_stage_kernel<1>");
+  }
+  if (sweeps_per_launch) *sweeps_per_launch = 1;
   return AMG_HIP_OK;
 }
 
@@ -1486,22 +1536,14 @@ amg_hip_status amg_hip_coarse_solve(int64_t n, const int32_t* colptr, const int3
   Sparse A = from_raw(n, n, colptr, rowind, val);
   std::string v = validate(A, "A");
   if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
-  BandFactor F;
-  std::string e = band_factor(A, (size_t)8 << 30, &F);
-  if (!e.empty()) return fail(AMG_HIP_EINVAL, e);
-  if (halfbw) *halfbw = F.w;
-  BandSchedule S;
-  e = band_schedule(F, &S);
-  if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
-  DevMem dsf, dsb, dd, df, dy, dx;
-  HIP_TRY(upload(dsf, S.sched_f.data(), S.sched_f.size()));
-  HIP_TRY(upload(dsb, S.sched_b.data(), S.sched_b.size()));
-  HIP_TRY(upload(dd, S.d.data(), S.d.size()));
+  CoarseOnDev C;
+  if ((st = upload_coarse(A, -1, &C)) != AMG_HIP_OK) return st;  // bit-exact forms only
+  if (halfbw) *halfbw = C.w;
+  DevMem df, dy, dx;
   HIP_TRY(upload(df, f, (size_t)n));
   HIP_TRY(dy.alloc(sizeof(double) * n));
   HIP_TRY(dx.alloc(sizeof(double) * n));
-  HIP_TRY(launch_band_solve(n, S.m, dsf.as<double>(), dsb.as<double>(), dd.as<double>(),
-                            df.as<double>(), dy.as<double>(), dx.as<double>(), nullptr));
+  HIP_TRY(launch_coarse(C, df.as<double>(), dy.as<double>(), dx.as<double>(), nullptr));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(x, dx.p, sizeof(double) * n, hipMemcpyDeviceToHost));
   return AMG_HIP_OK;

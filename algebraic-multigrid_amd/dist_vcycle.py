@@ -30,6 +30,7 @@ All compute goes through a `backend` object: HipBackend (torch device tensors +
 the C ABI's device-pointer launchers) in production; tests pass their own.
 """
 import os
+import sys
 import time
 
 import numpy as np
@@ -803,30 +804,72 @@ class DistributedVcycle:
 
 
 # --------------------------------------------------------------------- bench ---
+class TransportWatchdog:
+    """Bounds the time an alternative halo transport (hipIpc stream operations, in-graph
+    spin-flag kernels) may take.  They have never run on real xGMI links here, so a hang
+    must not be reported as success: on expiry the rank says which transport hung and
+    where (stderr), rank 0 may still print the RCCL (p2p) line it already has, and the
+    process leaves with status 3."""
+
+    EXIT_STATUS = 3
+
+    def __init__(self, rank, timeout_s, stash):
+        self.rank, self.timeout_s, self.stash = rank, float(timeout_s), stash
+        self._timer, self.mode = None, None
+
+    def arm(self, mode):
+        import threading
+        self.disarm()
+        self.mode = mode
+        self._timer = threading.Timer(self.timeout_s, self._expired)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+    def _expired(self):
+        st = self.stash
+        flag = None
+        try:
+            flag = st["dv"].timed_out() if st.get("dv") is not None else None
+        except Exception:
+            pass
+        sys.stderr.write(f"[dist_vcycle] rank {self.rank}: halo transport '{self.mode}' did not finish "
+                         f"within {self.timeout_s:.0f} s (device-side spin timeout flag: {flag}; "
+                         f"distributed levels: {st.get('n_dist')}); leaving with status "
+                         f"{self.EXIT_STATUS}\n")
+        sys.stderr.flush()
+        if self.rank == 0 and st.get("json") is not None:
+            print(st["json"], flush=True)
+        os._exit(self.EXIT_STATUS)
+
+
 def _result_line(args, world, L, dv, results, best, notes, rehearsal, avg_ms, sweep_bytes, t0,
                  layout=None):
-    from bench import HBM_PEAK_GBS
+    from bench import HBM_PEAK_GBS, metric_string
     dt, rss0, rss = results[best]
     roof = None
     if avg_ms:
-        achieved = sweep_bytes / (avg_ms * 1e-3) / 1e9
         lay, mat_bytes, rows = layout if layout else ("?", None, None)
         kern = {"dict": "dict_kernel<CSR_JACOBI> (dictionary-coded rows)",
                 "sell": "sell_kernel<CSR_JACOBI> (SELL-64 panels)",
                 "csr": "csr_stage_kernel<CSR_JACOBI> (LDS-staged CSR)"}.get(lay, "Jacobi sweep")
-        fmt = (mat_bytes + 24 * rows) if mat_bytes is not None else None
+        # bytes the timed kernel has to move (bench.fine_sweep_roofline): the dictionary-coded
+        # layout streams its matrix bytes + f + x + out, the CSR layouts the CSR formula
+        must = (mat_bytes + 24 * rows) if (lay == "dict" and mat_bytes is not None) else sweep_bytes
+        achieved = must / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": f"{kern}: rank 0's row block of the level-0 Jacobi sweep",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_ms,
-                "layout": lay, "format_bytes_per_launch": fmt,
-                "format_GBps": (fmt / (avg_ms * 1e-3) / 1e9) if fmt else None,
-                "note": "achieved/frac use the CSR-formula bytes (12 nnz + 28 n) of the rank's row "
-                        "block; the dictionary-coded layout moves format_bytes_per_launch, so frac "
-                        "can exceed 1 (see the N=1 line for the PMC-measured traffic)"}
+                "algorithmic_bytes_per_launch": must, "avg_launch_ms": avg_ms,
+                "layout": lay, "csr_formula_bytes_per_sweep": sweep_bytes,
+                "note": "per rank: rank 0's row block; PMC traffic is collected on the N=1 line"}
     n_dist = notes.get(best + "_distributed_levels", dv.n_dist)   # of the reported transport
     return {
-        "metric": "V-cycles/sec, 2D Poisson N=4096^2 (fine-grid smoother HBM GB/s under roofline)",
+        "metric": metric_string(args.n),
         "value": args.steps / dt, "unit": "V-cycles/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -902,14 +945,10 @@ def bench(args):
     notes = {}
     stash = {"json": None}
 
-    def bail():
-        if rank == 0 and stash["json"] is not None:
-            print(stash["json"], flush=True)
-        os._exit(0)
+    dog = TransportWatchdog(rank, args.comm_timeout, stash)
 
     if dv.n_dist and args.comm != "p2p":
         import json as _json
-        import threading
         stash["json"] = _json.dumps(_result_line(args, world, L, dv, results, "p2p", {"note": "alternative exchange hung"},
                                                  rehearsal, None, None, t0)) if rank == 0 else None
         # cheaper exchanges pay off on smaller levels (results do not depend on the
@@ -919,14 +958,16 @@ def bench(args):
                 "graph": [("graph", args.dist_min_rows_graph), ("graph@8x", 8 * args.dist_min_rows_graph)]}
         modes = cand["ipc"] + cand["graph"] if args.comm == "auto" else cand[args.comm]
         for mode, min_rows in modes:
-            dog = threading.Timer(args.comm_timeout, bail)
-            dog.daemon = True
-            dog.start()
+            stash["dv"], stash["n_dist"] = None, None
+            dog.arm(mode)
             try:
+                if os.environ.get("AMG_DIST_FORCE_HANG") == mode:   # test hook for the watchdog
+                    time.sleep(args.comm_timeout + 30)
                 dvx = DistributedVcycle(hier, b, be, rank, world, omega=args.omega,
                                         sweeps=args.sweeps, dist_min_rows=min_rows,
                                         host_staged=rehearsal, comm=mode.split("@")[0])
                 notes[mode + "_distributed_levels"] = dvx.n_dist
+                stash["dv"], stash["n_dist"] = dvx, dvx.n_dist
                 res = timed(dvx)
                 same = (res[1] == results["p2p"][1]) and (res[2] == results["p2p"][2]) and not dvx.timed_out()
                 flag = torch.tensor([1 if same else 0], dtype=torch.int32,
@@ -941,7 +982,7 @@ def bench(args):
             except IpcUnavailable as ex:
                 notes[mode] = f"unavailable: {ex}"
             finally:
-                dog.cancel()
+                dog.disarm()
     hier.close()
     best = min(results, key=lambda k: results[k][0])
     dt, rss0, rss = results[best]

@@ -26,6 +26,41 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CPU_FLAGS = ("-O2 -ffp-contract=off", "-O3 -march=native -ffp-contract=off")
+
+
+def metric_string(n):
+    return f"V-cycles/sec, 2D Poisson N={n}^2 (fine-grid smoother HBM GB/s under roofline)"
+
+
+def source_sha16():
+    """Identifies the kernel build a PMC record belongs to: hash of the device sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "kernels.hpp", "solver.cpp", "host_setup.cpp", "host_setup.hpp"):
+        with open(os.path.join(PKG, "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_prefix, n):
+    """HBM bytes per launch of the kernel whose name starts with `kernel_prefix`, from a
+    committed rocprofv3 PMC record (profiles/*_pmc_traffic.json; rocprofv3 cannot run inside
+    this process).  A record is only quoted for the build and the grid it was measured on:
+    its source_sha16 must equal the hash of the current device sources."""
+    import glob
+    sha = source_sha16()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        if rec.get("source_sha16") != sha or rec.get("n") != n:
+            continue
+        for key, k in rec.get("kernels", {}).items():
+            if key.startswith(kernel_prefix) and key.endswith("@L0"):
+                return k["traffic_bytes"], (f"profiles/{os.path.basename(path)[:-5]}.md [{key}]: " + rec["source"])
+    return None, f"no PMC record for this build (source_sha16 {sha}); see tools/pmc_traffic.py"
 
 
 def n_levels_for(n, coarsest_max=511):
@@ -39,29 +74,38 @@ def n_levels_for(n, coarsest_max=511):
 
 
 def cpu_baseline(args):
-    """The CPU oracle (Eigen-order restatement of the reference, 1 thread -- the
-    reference is serial) timed on a bounded sample of the same workload."""
+    """The CPU oracle (Eigen-order restatement of the reference, 1 thread -- the reference
+    is serial) timed on the benchmarked instance itself (--grid; SURVEY 8(d): vcycle() only,
+    1 warm-up, median), once per flag set of CPU_FLAGS.  `value` is the faster of the two."""
     from oracle import oracle as O
-    n = args.cpu_n
-    L = n_levels_for(n)
+    n = args.cpu_n or args.n
+    L = args.levels or n_levels_for(n)
     A, b = O.laplacian(n), O.rhs(n)
-    mg = O.Multigrid(A, b, L, smoother=O.SM_TRUE_JACOBI, smoother_iters=args.sweeps,
-                     omega=args.omega)
-    mg.time_vcycles(1)  # warm-up
-    reps = args.cpu_cycles
-    times = sorted(mg.time_vcycles(1) for _ in range(reps))
-    med = times[len(times) // 2]
-    scale = (n * n) / float(args.n * args.n)   # V-cycle cost is linear in the dofs
+    runs = {}
+    for flags in CPU_FLAGS:
+        lib = O.lib() if flags == CPU_FLAGS[0] else O.lib_variant(flags)
+        t0 = time.time()
+        mg = O.Multigrid(A, b, L, smoother=O.SM_TRUE_JACOBI, smoother_iters=args.sweeps,
+                         omega=args.omega, library=lib)
+        setup = time.time() - t0
+        mg.time_vcycles(1)  # warm-up
+        times = sorted(mg.time_vcycles(1) for _ in range(args.cpu_cycles))
+        del mg
+        runs[flags] = {"vcycles_per_sec": 1.0 / times[len(times) // 2], "setup_seconds": setup}
+    best = max(runs, key=lambda k: runs[k]["vcycles_per_sec"])
+    scale = (n * n) / float(args.n * args.n)   # 1 unless --cpu-n asks for a smaller sample
     return {
-        "value": (1.0 / med) * scale,
+        "value": runs[best]["vcycles_per_sec"] * scale,
         "unit": "V-cycles/s",
         "cores": 1,
         "host_cores": os.cpu_count(),
         "kind": "port",
-        "sample": (f"{reps} vcycle() calls (median) of the CPU oracle on the {n}x{n} instance of "
-                   f"the same workload ({L} levels, same smoother), rate scaled by "
-                   f"{n * n}/{args.n * args.n} dofs to the {args.n}x{args.n} problem; "
-                   f"measured {1.0 / med:.3f} V-cycles/s at {n}x{n}"),
+        "flags": best,
+        "by_flags": runs,
+        "sample": (f"{args.cpu_cycles} vcycle() calls (median, after 1 warm-up) of the CPU oracle "
+                   f"(g++ {best}) on the {n}x{n} instance ({L} levels, same smoother, same "
+                   f"omega)" + ("" if n == args.n else
+                                f", rate scaled by {n * n}/{args.n * args.n} dofs to {args.n}x{args.n}")),
     }
 
 
@@ -96,37 +140,16 @@ def run_single(args):
     mg.vcycle(args.steps)
     mg.sync()
     dt = time.perf_counter() - t1
-    # dominant kernel: level-0 Jacobi sweep, HIP events on the solver's stream
-    if args.smoother == "jacobi":
-        avg_ms, min_ms = mg.profile_fine_sweep(args.profile_launches)
-    else:
-        avg_ms, min_ms = float("nan"), float("nan")
     cyc_bytes, sweep_bytes = mg.cycle_bytes()
     rss = mg.rss()
-    if args.warmup >= 1 and args.smoother == "jacobi" and not (rss < rss0):
+    # every configuration must reduce rss over the timed cycles; the ratio is recorded
+    if args.warmup >= 1 and not (rss < rss0):
         raise SystemExit(f"V-cycle iteration is not converging (rss {rss0:.3e} -> {rss:.3e})")
     sizes = [mg.get_n_dofs(l) for l in range(L)]
-    achieved = sweep_bytes / (avg_ms * 1e-3) / 1e9
     lay, mat_bytes = mg.level_layout(0)
     lay_name = {amg.LAYOUT_CSR: "csr", amg.LAYOUT_SELL: "sell", amg.LAYOUT_DICT: "dict"}[lay]
-    # what the format has to move per sweep: matrix stream + f + x + out (8 B each per row)
-    format_bytes = mat_bytes + 24 * sizes[0]
-    kernel = {"dict": ("dict_kernel<CSR_JACOBI, 1 code word, 5 entries, nt, 2 rows/lane> (level-0 Jacobi sweep, "
-                       "dictionary-coded rows, one byte per row)", "r01h_pmc_traffic", "dict_kernel<1, 1, 5, true, 2>@L0"),
-              "sell": ("sell_kernel<CSR_JACOBI, idx16, nt> (level-0 Jacobi sweep, SELL-64 panels)",
-                       "r01c_pmc_traffic", "sell_kernel<1, true, true>@16777216"),
-              "csr": ("csr_stage_kernel<CSR_JACOBI> (level-0 Jacobi sweep, LDS-staged CSR)", None, None)}[lay_name]
-    # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run
-    # inside this process); only quoted for the configuration it was measured on.
-    traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", f"{kernel[1]}.json")
-    if kernel[1] and os.path.exists(pmc) and args.n == 4096 and not args.no_nt:
-        rec = json.load(open(pmc))
-        k = rec["kernels"].get(kernel[2])
-        if k and rec.get("n") == args.n:
-            traffic, traffic_src = k["traffic_bytes"], f"profiles/{kernel[1]}.md: " + rec["source"]
     out = {
-        "metric": "V-cycles/sec, 2D Poisson N=4096^2 (fine-grid smoother HBM GB/s under roofline)",
+        "metric": metric_string(args.n),
         "value": args.steps / dt,
         "unit": "V-cycles/s",
         "n_gpus": 1,
@@ -139,41 +162,24 @@ def run_single(args):
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": (f"2D 5-point Poisson {args.n}x{args.n} (Grid::laplacian/rhs), true Jacobi "
-                         f"smoother omega={args.omega} {args.sweeps}+{args.sweeps} sweeps, "
-                         f"{L}-level V-cycle, coarsest {sizes[-1]} dofs, fp64, 1xMI355X"),
+            "workload": (f"2D 5-point Poisson {args.n}x{args.n} (Grid::laplacian/rhs), "
+                         + (f"true Jacobi smoother omega={args.omega} {args.sweeps}+{args.sweeps} sweeps"
+                            if args.smoother == "jacobi" else "multicolour symmetric GS 1+1 passes")
+                         + f", {L}-level V-cycle, coarsest {sizes[-1]} dofs, fp64, 1xMI355X; "
+                           "smoother has no counterpart in the reference: pinned to the oracle twin"),
             "n": args.n, "levels": L, "smoother": args.smoother, "omega": args.omega,
-            "sweeps": args.sweeps, "graph": not args.no_graph, "fast_coarse_solve": args.fast_coarse,
-            "cycle_algorithmic_bytes": cyc_bytes, "cycle_GBps": cyc_bytes / (dt / args.steps) / 1e9,
-            "setup_seconds": setup_s, "rss_after_warmup": rss0, "rss_after_steps": rss,
+            "sweeps": args.sweeps, "graph": not args.no_graph, "coarse_solve": mg.coarse_solve_kind(),
+            "layout": lay_name, "setup_seconds": setup_s,
+            "rss_after_warmup": rss0, "rss_after_steps": rss,
+            "rss_ratio_per_cycle": (rss / rss0) ** (1.0 / args.steps) if rss0 > 0 else None,
+            "csr_formula_cycle_bytes": cyc_bytes,
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": kernel[0],
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": sweep_bytes,
-            "layout": lay_name,
-            "format_bytes_per_launch": format_bytes,
-            "format_GBps": format_bytes / (avg_ms * 1e-3) / 1e9,
-            "hbm_GBps_measured": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
-            "hbm_frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-            "note": ("achieved/frac use the CSR-formula bytes of SURVEY 8(d) (12 nnz + 28 n per sweep), i.e. "
-                     "the CSR-equivalent rate; the dictionary-coded layout moves format_bytes_per_launch "
-                     "(1 B of row type + f + x + out per row), so frac can exceed 1 -- hbm_*_measured is the "
-                     "PMC traffic over the same launch time against the 8 TB/s peak") if lay_name == "dict" else None,
-            "avg_launch_ms": avg_ms,
-            "min_launch_ms": min_ms,
-            "launches_timed": args.profile_launches,
-        },
+        "roofline": fine_sweep_roofline(amg, mg, args, lay_name, mat_bytes, sizes[0], sweep_bytes)
+        if args.smoother == "jacobi" else None,
     }
     mg.close()
-    # the same workload with the level matrices as plain CSR panels (SELL-64, the layout the
-    # CSR-formula bytes describe): a second, shorter measurement in the same run
+    # the same workload with the level matrices as plain CSR panels (SELL-64): the layout
+    # SURVEY 8(d)'s CSR-formula bytes describe; a second, shorter measurement in the same run
     if lay_name == "dict" and args.smoother == "jacobi" and not args.no_csr_ref:
         colptr, rowind, val = amg.laplacian(args.n)
         ref = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_JACOBI, smoother_iters=args.sweeps,
@@ -186,19 +192,63 @@ def run_single(args):
         ref.vcycle(k)
         ref.sync()
         dt2 = time.perf_counter() - t2
-        ref_ms, _ = ref.profile_fine_sweep(max(8, args.profile_launches // 2))
+        lay2, mat2 = ref.level_layout(0)
+        roof2 = fine_sweep_roofline(amg, ref, args, "sell", mat2, sizes[0], sweep_bytes,
+                                    launches=max(8, args.profile_launches // 2))
         rss_ref = ref.rss()
         ref.close()
         out["config"]["csr_layout_reference"] = {
             "layout": "sell (CSR sliced into 64-row panels, 16-bit relative columns)",
             "vcycles_per_sec": k / dt2, "ms_per_step": dt2 / k * 1e3, "steps": k,
-            "fine_sweep_ms": ref_ms, "fine_sweep_GBps": sweep_bytes / (ref_ms * 1e-3) / 1e9,
-            "fine_sweep_frac_of_peak": sweep_bytes / (ref_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "rss_after_warmup_plus_steps": rss_ref,
+            "rss_after_warmup_plus_steps": rss_ref, "roofline": roof2,
         }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args)
     return out
+
+
+def fine_sweep_roofline(amg, mg, args, lay_name, mat_bytes, n0, csr_formula_bytes, launches=None):
+    """`roofline` object of the dominant kernel: the level-0 Jacobi sweep(s).
+
+    achieved = bytes ONE LAUNCH has to move / its average duration (HIP events on the solver's
+    stream, amg_hip_profile_fine_sweep).  The bytes follow from what the kernel reads and
+    writes, never from a layout it does not stream:
+      sell / csr: SURVEY 8(d)'s CSR formula, 12 nnz + 28 n per sweep;
+      dict:       matrix stream (1 B row type per row) + f + x + out (8 B each per row);
+      a launch that does k sweeps in one pass (temporal blocking) still has to move
+      f + x + out once, so its bytes are those of ONE sweep -- the extra sweeps are the
+      traffic it saves, and they show up in V-cycles/s, not in this fraction."""
+    avg_ms, min_ms, sweeps_per_launch, kname = mg.profile_fine_sweep(launches or args.profile_launches)
+    if lay_name == "dict":
+        must_move = mat_bytes + 24 * n0
+        model = "n*(1 B row type + f + x + out) + tables"
+    else:
+        must_move = csr_formula_bytes
+        model = "12 nnz + 28 n (SURVEY 8(d) CSR formula)"
+    achieved = must_move / (avg_ms * 1e-3) / 1e9
+    traffic, traffic_src = (None, "not quoted: non-default kernel switches")
+    if not args.no_nt:
+        traffic, traffic_src = pmc_traffic(kname.split("<")[0], args.n)
+    return {
+        "bound": "hbm",
+        "kernel": kname,
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": must_move,
+        "bytes_model": model,
+        "sweeps_per_launch": sweeps_per_launch,
+        "layout": lay_name,
+        "csr_formula_bytes_per_sweep": csr_formula_bytes,
+        "csr_equivalent_GBps": csr_formula_bytes * sweeps_per_launch / (avg_ms * 1e-3) / 1e9,
+        "hbm_GBps_measured": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+        "avg_launch_ms": avg_ms,
+        "min_launch_ms": min_ms,
+        "launches_timed": launches or args.profile_launches,
+    }
 
 
 def main():
@@ -226,8 +276,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-csr-ref", action="store_true",
                     help="skip the second measurement with the plain-CSR (SELL-64) layout")
-    ap.add_argument("--cpu-n", type=int, default=2048, help="grid of the CPU baseline sample")
-    ap.add_argument("--cpu-cycles", type=int, default=5)
+    ap.add_argument("--cpu-n", type=int, default=0,
+                    help="grid of the CPU baseline sample (0 = the benchmarked --grid itself)")
+    ap.add_argument("--cpu-cycles", type=int, default=3)
     ap.add_argument("--profile-launches", type=int, default=40)
     ap.add_argument("--comm", choices=["auto", "p2p", "ipc", "graph"], default="auto",
                     help="multi-GPU halo exchange: p2p = torch.distributed isend/irecv (RCCL); ipc = "

@@ -91,6 +91,16 @@ class Multigrid {
       // user-defined SmootherBase: its smooth() runs on the host, everything else of the
       // V-cycle on the device; the device-side smoother is never used
       custom_smoother = true;
+    }
+    // A reference smoother built with the (tolerance, every, n_iters) constructors checks rss
+    // every `compute_error_every_n_iters` sweeps, may leave its loop early and prints its
+    // convergence line on EVERY smooth() call (smoother.hpp:195-212).  The fused device
+    // V-cycle runs a fixed number of sweeps and prints nothing, so such a smoother goes
+    // through its own smooth() level by level: same sweep counts, same lines.
+    if (!custom_smoother && opt.smoother != AMG_HIP_SM_JACOBI &&
+        smoother->compute_error_every_n_iters != 0)
+      custom_smoother = true;
+    if (custom_smoother) {
       opt.smoother = AMG_HIP_SM_JACOBI;
       opt.smoother_iters = 0;
     }
@@ -123,18 +133,25 @@ class Multigrid {
                                         A0.valuePtr(), b.data(), (int32_t)n_levels, Pc.data(),
                                         Pr.data(), Pv.data(), Rc.data(), Rr.data(), Rv.data(), &opt,
                                         &handle));
-    // host copies of the level matrices (get_coefficient_matrix returns const&)
-    level_to_coefficient_matrix.resize(n_levels);
-    for (size_t l = 0; l < n_levels; ++l) {
-      const size_t n = level_to_n_dofs[l];
-      const int64_t nnz = amg_hip_get_level_nnz(handle, (int32_t)l);
-      std::vector<int32_t> cp(n + 1), ri((size_t)nnz);
-      std::vector<double> v((size_t)nnz);
-      detail::check(amg_hip_get_level_matrix(handle, (int32_t)l, cp.data(), ri.data(), v.data()));
-      level_to_coefficient_matrix[l] = detail::make_sparse<EleType>(n, n, cp.data(), ri.data(), v.data());
+    // host copies of the level matrices (get_coefficient_matrix returns const&); the
+    // destructor does not run when a constructor throws, so the handle is released here
+    try {
+      level_to_coefficient_matrix.resize(n_levels);
+      for (size_t l = 0; l < n_levels; ++l) {
+        const size_t n = level_to_n_dofs[l];
+        const int64_t nnz = amg_hip_get_level_nnz(handle, (int32_t)l);
+        std::vector<int32_t> cp(n + 1), ri((size_t)nnz);
+        std::vector<double> v((size_t)nnz);
+        detail::check(amg_hip_get_level_matrix(handle, (int32_t)l, cp.data(), ri.data(), v.data()));
+        level_to_coefficient_matrix[l] = detail::make_sparse<EleType>(n, n, cp.data(), ri.data(), v.data());
+      }
+      level_to_soln.resize(n_levels);
+      level_to_rhs.resize(n_levels);
+    } catch (...) {
+      amg_hip_destroy(handle);
+      handle = nullptr;
+      throw;
     }
-    level_to_soln.resize(n_levels);
-    level_to_rhs.resize(n_levels);
   }
 
   // reference multigrid.hpp:263-305

@@ -95,10 +95,12 @@ typedef struct {
   int32_t fuse_prolong;    /* 1: apply the prolongation inside the first post-smoothing
                               Jacobi sweep (bit-identical; measured slower, off)  */
   int32_t fast_coarse_solve; /* 1: solve the coarsest system with the partitioned
-                              (parallel) form of the banded LDL^T: depth ~2c+P steps
-                              instead of n.  Same direct solve, different rounding
-                              order: agrees with the sequential substitution to
-                              ~1e-14 relative, not bit for bit.  Default 0.          */
+                              (parallel) form of the banded LDL^T whenever it applies
+                              (half-bandwidth <= 63): depth ~2c+P steps instead of n.
+                              Same direct solve, different rounding order: agrees with
+                              the sequential substitution to ~1e-14 relative, not bit
+                              for bit.  Default 0 = by size: partitioned from 4096
+                              coarsest rows on (see exact_coarse_solve).             */
   int32_t host_galerkin;   /* 1: build the Galerkin products R (A P) on the host instead of
                               on the device (same entries, same bits; the device path
                               is taken for LinearInterpolator operators only)        */
@@ -108,6 +110,18 @@ typedef struct {
                               by default (0) the fused residual+restriction kernel does
                               not store r on the levels where it runs, and reading it
                               there returns AMG_HIP_EINVAL.                            */
+  int32_t exact_coarse_solve; /* 1: always the sequential substitution (bit-exact against
+                              the row-oriented LDL^T solve of the oracle), whatever the
+                              size of the coarsest level.  Default 0.                   */
+  int32_t exact_gs;        /* SparseGaussSeidel / AMG::Jacobi / SOR (lexicographic sweeps,
+                              smoother.hpp:148-174).  1: always the dependency-scheduled
+                              exact kernel (bit-exact, one latency-bound workgroup).
+                              0 (default): levels of more than 65536 rows whose matrix
+                              is dictionary-coded with one chained lower neighbour run
+                              the line-scan form (the in-line recurrence u_k = c_k +
+                              q_k u_{k-1} solved by a parallel affine scan: same sweep,
+                              different rounding order, ~1e-13 relative); smaller
+                              problems keep the exact kernel.                          */
   void* stream;            /* hipStream_t to run on; NULL (default) = the solver creates
                               and owns a non-blocking stream.  A caller that already
                               orders its device work on a stream (torch's current
@@ -237,6 +251,11 @@ amg_hip_status amg_hip_level_layout(const amg_hip_solver* s, int32_t level, int3
 
 /* Half-bandwidth of the factored coarsest operator. */
 int64_t amg_hip_coarse_halfbw(const amg_hip_solver* s);
+/* Which device form of the coarsest solve (multigrid.hpp:287-288) the solver uses:
+ * 0 = one-wave sequential substitution (half-bandwidth <= 63, bit-exact),
+ * 1 = partitioned / parallel (fast_coarse_solve or >= 4096 rows),
+ * 2 = blocked sequential substitution for any half-bandwidth (bit-exact).          */
+int32_t amg_hip_coarse_solve_kind(const amg_hip_solver* s);
 /* Multicolour smoother: colour of every dof of `level` (n_dofs int32) and the
  * colour count, so a CPU twin can replay the same colouring.                   */
 amg_hip_status amg_hip_get_colors(const amg_hip_solver* s, int32_t level,
@@ -266,6 +285,10 @@ amg_hip_status amg_hip_cycle_bytes(const amg_hip_solver* s, double* cycle_bytes,
  * solution is restored afterwards.                                            */
 amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
                                           double* avg_ms, double* min_ms);
+/* Name of the kernel amg_hip_profile_fine_sweep times (as rocprofv3 prints it, without the
+ * namespace) and the number of Jacobi sweeps over level 0 one launch of it performs.  */
+amg_hip_status amg_hip_fine_sweep_info(const amg_hip_solver* s, char* name, int32_t name_cap,
+                                       int32_t* sweeps_per_launch);
 
 /* ---- stand-alone plug-in operations on host arrays (run on the device) -----
  * SmootherBase::smooth(A, u, b), smoother.hpp:63-65, for the built-in kinds.

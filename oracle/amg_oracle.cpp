@@ -422,6 +422,33 @@ void multicolor_gs(const Csc& A, double* u, const double* b, const idx_t* color,
   }
 }
 
+// First-fit colouring in row order; neighbours = numerically non-zero off-diagonal entries
+// of column k and of row k (so that a structurally non-symmetric A is handled too).
+void greedy_colors(const Csc& A, std::vector<idx_t>* color, idx_t* n_colors) {
+  const Csc T = transpose(A);
+  const int64_t n = A.cols;
+  color->assign((size_t)n, -1);
+  idx_t nc = 0;
+  std::vector<int64_t> mark;
+  for (int64_t k = 0; k < n; ++k) {
+    for (const Csc* S : {&A, &T})
+      for (idx_t p = S->colptr[k]; p < S->colptr[k + 1]; ++p) {
+        const idx_t j = S->rowind[p];
+        if (j == k || S->val[p] == 0.0) continue;
+        const idx_t c = (*color)[j];
+        if (c >= 0) mark[c] = k;
+      }
+    idx_t c = 0;
+    while (c < nc && mark[c] == k) ++c;
+    if (c == nc) {
+      ++nc;
+      mark.push_back(-1);
+    }
+    (*color)[k] = c;
+  }
+  *n_colors = nc;
+}
+
 // --------------------------------------------------- coarse direct solver ----
 // multigrid.hpp:33,240-243,287-288 use Eigen::SimplicialLDLT (AMD ordering).
 // Restated as an un-permuted banded LDL^T (A_L is symmetric negative definite,
@@ -555,6 +582,9 @@ void mg_smooth(Multigrid* M, size_t l) {
     case SM_SOR: sor_smooth(A, u, f, M->omega, 1e-9, 0, M->sm_iters); break;
     case SM_TRUE_JACOBI: true_jacobi(A, u, f, M->omega, M->sm_iters); break;
     case SM_MULTICOLOR:
+      // no colouring handed over (orc_mg_set_colors): colour greedily here -- first fit in
+      // row order over the numerically non-zero pattern of A and A^T
+      if ((int64_t)M->color[l].size() != A.rows) greedy_colors(A, &M->color[l], &M->n_colors[l]);
       multicolor_gs(A, u, f, M->color[l].data(), M->n_colors[l], M->sm_iters);
       break;
   }

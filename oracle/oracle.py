@@ -37,75 +37,106 @@ def _p64(a):
     return None if a is None else a.ctypes.data_as(_f64p)
 
 
+def _bind(L):
+    L.orc_grid_spacing_h.restype = C.c_double
+    L.orc_grid_spacing_h.argtypes = [C.c_uint64]
+    L.orc_points_n_from_grid_spacing_h.restype = C.c_uint64
+    L.orc_points_n_from_grid_spacing_h.argtypes = [C.c_double]
+    L.orc_laplacian.restype = C.c_int64
+    L.orc_laplacian.argtypes = [C.c_int, C.c_uint64, _i32p, _i32p, _f64p]
+    L.orc_rhs.restype = None
+    L.orc_rhs.argtypes = [C.c_int, C.c_uint64, _f64p]
+    L.orc_n_H_from_n_h.restype = C.c_uint64
+    L.orc_n_H_from_n_h.argtypes = [C.c_uint64]
+    L.orc_make_P.restype = C.c_int64
+    L.orc_make_P.argtypes = [C.c_uint64, C.c_uint64, _i32p, _i32p, _f64p]
+    L.orc_transpose.restype = None
+    L.orc_transpose.argtypes = [C.c_int64, C.c_int64, _i32p, _i32p, _f64p,
+                                _i32p, _i32p, _f64p]
+    L.orc_residual.restype = None
+    L.orc_residual.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, _f64p]
+    L.orc_spmv.restype = None
+    L.orc_spmv.argtypes = [C.c_int64, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
+    L.orc_rss.restype = C.c_double
+    L.orc_rss.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
+    L.orc_smooth.restype = C.c_uint64
+    L.orc_smooth.argtypes = [C.c_int, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p,
+                             C.c_double, C.c_double, C.c_uint64, C.c_uint64,
+                             _i32p, C.c_int32, C.POINTER(C.c_int)]
+    L.orc_spgs_sweep.restype = None
+    L.orc_spgs_sweep.argtypes = [C.c_int, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
+    L.orc_band_solve.restype = C.c_int64
+    L.orc_band_solve.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
+    L.orc_mg_create.restype = C.c_void_p
+    L.orc_mg_create.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_uint64]
+    L.orc_mg_destroy.restype = None
+    L.orc_mg_destroy.argtypes = [C.c_void_p]
+    L.orc_mg_set_smoother.restype = None
+    L.orc_mg_set_smoother.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_double]
+    L.orc_mg_set_colors.restype = None
+    L.orc_mg_set_colors.argtypes = [C.c_void_p, C.c_uint64, _i32p, C.c_int32]
+    L.orc_mg_n_dofs.restype = C.c_uint64
+    L.orc_mg_n_dofs.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_mg_level_nnz.restype = C.c_int64
+    L.orc_mg_level_nnz.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_mg_level_matrix.restype = None
+    L.orc_mg_level_matrix.argtypes = [C.c_void_p, C.c_uint64, _i32p, _i32p, _f64p]
+    L.orc_mg_transfer_nnz.restype = C.c_int64
+    L.orc_mg_transfer_nnz.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+    L.orc_mg_transfer.restype = None
+    L.orc_mg_transfer.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _i32p, _i32p, _f64p]
+    L.orc_mg_get_vec.restype = None
+    L.orc_mg_get_vec.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _f64p]
+    L.orc_mg_set_vec.restype = None
+    L.orc_mg_set_vec.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _f64p]
+    L.orc_mg_coarse_halfbw.restype = C.c_int64
+    L.orc_mg_coarse_halfbw.argtypes = [C.c_void_p]
+    L.orc_mg_vcycle.restype = None
+    L.orc_mg_vcycle.argtypes = [C.c_void_p]
+    L.orc_mg_rss.restype = C.c_double
+    L.orc_mg_rss.argtypes = [C.c_void_p]
+    L.orc_mg_solve.restype = C.c_uint64
+    L.orc_mg_solve.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint64,
+                               C.POINTER(C.c_int), _f64p, _f64p, C.c_uint64]
+    L.orc_mg_time_vcycles.restype = C.c_double
+    L.orc_mg_time_vcycles.argtypes = [C.c_void_p, C.c_uint64]
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
-        L.orc_grid_spacing_h.restype = C.c_double
-        L.orc_grid_spacing_h.argtypes = [C.c_uint64]
-        L.orc_points_n_from_grid_spacing_h.restype = C.c_uint64
-        L.orc_points_n_from_grid_spacing_h.argtypes = [C.c_double]
-        L.orc_laplacian.restype = C.c_int64
-        L.orc_laplacian.argtypes = [C.c_int, C.c_uint64, _i32p, _i32p, _f64p]
-        L.orc_rhs.restype = None
-        L.orc_rhs.argtypes = [C.c_int, C.c_uint64, _f64p]
-        L.orc_n_H_from_n_h.restype = C.c_uint64
-        L.orc_n_H_from_n_h.argtypes = [C.c_uint64]
-        L.orc_make_P.restype = C.c_int64
-        L.orc_make_P.argtypes = [C.c_uint64, C.c_uint64, _i32p, _i32p, _f64p]
-        L.orc_transpose.restype = None
-        L.orc_transpose.argtypes = [C.c_int64, C.c_int64, _i32p, _i32p, _f64p,
-                                    _i32p, _i32p, _f64p]
-        L.orc_residual.restype = None
-        L.orc_residual.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, _f64p]
-        L.orc_spmv.restype = None
-        L.orc_spmv.argtypes = [C.c_int64, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
-        L.orc_rss.restype = C.c_double
-        L.orc_rss.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
-        L.orc_smooth.restype = C.c_uint64
-        L.orc_smooth.argtypes = [C.c_int, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p,
-                                 C.c_double, C.c_double, C.c_uint64, C.c_uint64,
-                                 _i32p, C.c_int32, C.POINTER(C.c_int)]
-        L.orc_spgs_sweep.restype = None
-        L.orc_spgs_sweep.argtypes = [C.c_int, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
-        L.orc_band_solve.restype = C.c_int64
-        L.orc_band_solve.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
-        L.orc_mg_create.restype = C.c_void_p
-        L.orc_mg_create.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_uint64]
-        L.orc_mg_destroy.restype = None
-        L.orc_mg_destroy.argtypes = [C.c_void_p]
-        L.orc_mg_set_smoother.restype = None
-        L.orc_mg_set_smoother.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_double]
-        L.orc_mg_set_colors.restype = None
-        L.orc_mg_set_colors.argtypes = [C.c_void_p, C.c_uint64, _i32p, C.c_int32]
-        L.orc_mg_n_dofs.restype = C.c_uint64
-        L.orc_mg_n_dofs.argtypes = [C.c_void_p, C.c_uint64]
-        L.orc_mg_level_nnz.restype = C.c_int64
-        L.orc_mg_level_nnz.argtypes = [C.c_void_p, C.c_uint64]
-        L.orc_mg_level_matrix.restype = None
-        L.orc_mg_level_matrix.argtypes = [C.c_void_p, C.c_uint64, _i32p, _i32p, _f64p]
-        L.orc_mg_transfer_nnz.restype = C.c_int64
-        L.orc_mg_transfer_nnz.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
-        L.orc_mg_transfer.restype = None
-        L.orc_mg_transfer.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _i32p, _i32p, _f64p]
-        L.orc_mg_get_vec.restype = None
-        L.orc_mg_get_vec.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _f64p]
-        L.orc_mg_set_vec.restype = None
-        L.orc_mg_set_vec.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _f64p]
-        L.orc_mg_coarse_halfbw.restype = C.c_int64
-        L.orc_mg_coarse_halfbw.argtypes = [C.c_void_p]
-        L.orc_mg_vcycle.restype = None
-        L.orc_mg_vcycle.argtypes = [C.c_void_p]
-        L.orc_mg_rss.restype = C.c_double
-        L.orc_mg_rss.argtypes = [C.c_void_p]
-        L.orc_mg_solve.restype = C.c_uint64
-        L.orc_mg_solve.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint64,
-                                   C.POINTER(C.c_int), _f64p, _f64p, C.c_uint64]
-        L.orc_mg_time_vcycles.restype = C.c_double
-        L.orc_mg_time_vcycles.argtypes = [C.c_void_p, C.c_uint64]
-        _lib = L
+        _lib = _bind(C.CDLL(_LIB_PATH))
     return _lib
+
+
+_variants = {}
+
+
+def lib_variant(flags):
+    """The same restatement compiled with other optimisation flags (bench.py times the
+    CPU baseline both as -O2 and as -O3 -march=native).  Built on the machine
+    that runs it (-march=native must not travel), under oracle/_build/."""
+    import hashlib
+    import platform
+    if flags in _variants:
+        return _variants[flags]
+    try:
+        cpu = open("/proc/cpuinfo").read().split("flags", 1)[1].split("\n", 1)[0]
+    except Exception:
+        cpu = platform.processor()
+    src = os.path.join(_HERE, "amg_oracle.cpp")
+    tag = hashlib.sha256((flags + cpu + open(src).read()).encode()).hexdigest()[:12]
+    out_dir = os.path.join(_HERE, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, f"libamg_oracle_{tag}.so")
+    if not os.path.exists(path):
+        tmp = path + f".{os.getpid()}.tmp"
+        subprocess.check_call(["g++"] + flags.split() + ["-fPIC", "-std=c++17", "-shared", "-o", tmp, src])
+        os.replace(tmp, path)
+    _variants[flags] = _bind(C.CDLL(path))
+    return _variants[flags]
 
 
 class CSC:
@@ -223,33 +254,34 @@ class Multigrid:
     """Restatement of AMG::Multigrid<double> (multigrid.hpp) with
     LinearInterpolator and a selectable smoother (default SparseGaussSeidel())."""
 
-    def __init__(self, A, b, n_levels, smoother=SM_SPGS, smoother_iters=1, omega=1.0):
-        self._h = lib().orc_mg_create(A.rows, _p32(A.colptr), _p32(A.rowind),
+    def __init__(self, A, b, n_levels, smoother=SM_SPGS, smoother_iters=1, omega=1.0, library=None):
+        self._L = library or lib()
+        self._h = self._L.orc_mg_create(A.rows, _p32(A.colptr), _p32(A.rowind),
                                       _p64(A.val), _p64(np.ascontiguousarray(b)), n_levels)
         if not self._h:
             raise ValueError("orc_mg_create failed")
         self.n_levels = n_levels
-        lib().orc_mg_set_smoother(self._h, smoother, smoother_iters, omega)
+        self._L.orc_mg_set_smoother(self._h, smoother, smoother_iters, omega)
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_mg_destroy(self._h)
+            self._L.orc_mg_destroy(self._h)
             self._h = None
 
     def set_colors(self, level, color, n_colors):
         c = np.ascontiguousarray(color, dtype=np.int32)
-        lib().orc_mg_set_colors(self._h, level, _p32(c), n_colors)
+        self._L.orc_mg_set_colors(self._h, level, _p32(c), n_colors)
 
     def n_dofs(self, level):
-        return int(lib().orc_mg_n_dofs(self._h, level))
+        return int(self._L.orc_mg_n_dofs(self._h, level))
 
     def level_matrix(self, level):
         n = self.n_dofs(level)
-        nnz = lib().orc_mg_level_nnz(self._h, level)
+        nnz = self._L.orc_mg_level_nnz(self._h, level)
         colptr = np.empty(n + 1, np.int32)
         rowind = np.empty(nnz, np.int32)
         val = np.empty(nnz, np.float64)
-        lib().orc_mg_level_matrix(self._h, level, _p32(colptr), _p32(rowind), _p64(val))
+        self._L.orc_mg_level_matrix(self._h, level, _p32(colptr), _p32(rowind), _p64(val))
         return CSC(n, n, colptr, rowind, val)
 
     def transfer(self, level, which):
@@ -257,31 +289,31 @@ class Multigrid:
         w = 1 if which == "R" else 0
         n_h, n_H = self.n_dofs(level), self.n_dofs(level + 1)
         rows, cols = (n_H, n_h) if w else (n_h, n_H)
-        nnz = lib().orc_mg_transfer_nnz(self._h, level, w)
+        nnz = self._L.orc_mg_transfer_nnz(self._h, level, w)
         colptr = np.empty(cols + 1, np.int32)
         rowind = np.empty(nnz, np.int32)
         val = np.empty(nnz, np.float64)
-        lib().orc_mg_transfer(self._h, level, w, _p32(colptr), _p32(rowind), _p64(val))
+        self._L.orc_mg_transfer(self._h, level, w, _p32(colptr), _p32(rowind), _p64(val))
         return CSC(rows, cols, colptr, rowind, val)
 
     def get_vec(self, level, which):
         out = np.empty(self.n_dofs(level), np.float64)
-        lib().orc_mg_get_vec(self._h, level, {"u": 0, "f": 1, "r": 2}[which], _p64(out))
+        self._L.orc_mg_get_vec(self._h, level, {"u": 0, "f": 1, "r": 2}[which], _p64(out))
         return out
 
     def set_vec(self, level, which, v):
         v = np.ascontiguousarray(v, dtype=np.float64)
         assert v.size == self.n_dofs(level)
-        lib().orc_mg_set_vec(self._h, level, {"u": 0, "f": 1, "r": 2}[which], _p64(v))
+        self._L.orc_mg_set_vec(self._h, level, {"u": 0, "f": 1, "r": 2}[which], _p64(v))
 
     def coarse_halfbw(self):
-        return int(lib().orc_mg_coarse_halfbw(self._h))
+        return int(self._L.orc_mg_coarse_halfbw(self._h))
 
     def vcycle(self):
-        lib().orc_mg_vcycle(self._h)
+        self._L.orc_mg_vcycle(self._h)
 
     def rss(self):
-        return lib().orc_mg_rss(self._h)
+        return self._L.orc_mg_rss(self._h)
 
     def solve(self, tol=1e-9, every=10, n_iters=100):
         """Returns (iters, converged, last_rss, trajectory-of-rss-checks)."""
@@ -289,10 +321,10 @@ class Multigrid:
         last = C.c_double(0)
         cap = n_iters // max(every, 1) + 1
         traj = np.zeros(cap, np.float64)
-        it = lib().orc_mg_solve(self._h, tol, every, n_iters, C.byref(conv),
+        it = self._L.orc_mg_solve(self._h, tol, every, n_iters, C.byref(conv),
                                 C.byref(last), _p64(traj), cap)
         k = int(it) // every
         return int(it), bool(conv.value), last.value, traj[:k].copy()
 
     def time_vcycles(self, n):
-        return lib().orc_mg_time_vcycles(self._h, n)
+        return self._L.orc_mg_time_vcycles(self._h, n)

@@ -214,3 +214,25 @@ def test_sharded_3d_large_halos_on_one_gpu(tmp_path, oracle, comm):
     for _ in range(cycles):
         ref.vcycle()
     assert np.array_equal(got["u"], ref.get_vec(0, "u"))
+
+
+def test_transport_watchdog_exits_nonzero_and_names_the_transport():
+    """a hung alternative halo transport must not be reported as rc 0.  The
+    watchdog of bench.py --gpus N is armed in a child process that then 'hangs'; the child
+    has to leave with status 3, name the transport on stderr, and rank 0 may still print the
+    RCCL line it already had."""
+    import subprocess
+    import sys
+    pkg = os.path.join(ROOT, "algebraic-multigrid_amd")
+    code = (
+        "import sys, time; sys.path.insert(0, %r); import dist_vcycle as d;"
+        "w = d.TransportWatchdog(0, 0.3, {'json': '{\"p2p\": 1}', 'dv': None, 'n_dist': 2});"
+        "w.arm('graph'); time.sleep(20); print('not reached')" % pkg)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3, (p.returncode, p.stderr[-400:])
+    assert "halo transport 'graph'" in p.stderr and "status 3" in p.stderr
+    assert '{"p2p": 1}' in p.stdout and "not reached" not in p.stdout
+    # disarmed in time: normal exit
+    code2 = code.replace("time.sleep(20)", "w.disarm(); time.sleep(0.6)")
+    p = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "not reached" in p.stdout

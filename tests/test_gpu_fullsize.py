@@ -19,7 +19,9 @@ def test_config2_full_size_vs_oracle(amg, oracle):
     n, L = 1024, 6
     A, b = oracle.laplacian(n), oracle.rhs(n)
     ref = oracle.Multigrid(A, b, L)
-    mg = amg.Multigrid(*csc(A), b, L)
+    # parity mode: exact lexicographic GS kernel and sequential coarse substitution (the
+    # defaults at this size are the line-scan sweeps and the partitioned solve, 1e-10 class)
+    mg = amg.Multigrid(*csc(A), b, L, exact_coarse_solve=True, exact_gs=True)
     sizes = [mg.get_n_dofs(l) for l in range(L)]
     assert sizes == [1048576, 524287, 262143, 131071, 65535, 32767]
     nnz = [mg.get_coefficient_matrix(l)[1].size for l in range(L)]

