@@ -611,7 +611,8 @@ def test_vcycle_random_band_operators(amg, oracle):
         A = oracle.CSC(n, n, cp, np.array(ri, dtype=np.int32), np.array(va))
         b = 1.0 + rng.random(n)
         ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=sweeps, omega=0.55)
-        mg = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=sweeps, omega=0.55)
+        mg = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=sweeps, omega=0.55,
+                           exact_coarse_solve=True)   # bit-exact bar: sequential substitution
         for c in range(2):
             ref.vcycle()
             mg.vcycle()
