@@ -101,7 +101,8 @@ _SIGS = {
     "amg_hip_zero_vec": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "amg_hip_coarse_halfbw": (C.c_int64, [C.c_void_p]),
     "amg_hip_coarse_solve_kind": (C.c_int32, [C.c_void_p]),
-    "amg_hip_fine_sweep_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _i32p]),
+    "amg_hip_fine_sweep_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _i32p, _f64p]),
+    "amg_hip_set_patch_min_rows": (None, [C.c_int64]),
     "amg_hip_level_layout": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "amg_hip_get_colors": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p]),
     "amg_hip_level_op": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
@@ -233,6 +234,10 @@ def dict_probe(rowptr, col, val, ncols, diag_shift=0):
         return None
     _chk(st)
     return a.value, b.value, c.value
+
+
+def set_patch_min_rows(rows):
+    lib().amg_hip_set_patch_min_rows(int(rows))
 
 
 def set_row_types(on):
@@ -426,9 +431,9 @@ class Multigrid:
         a, b = C.c_double(0), C.c_double(0)
         _chk(lib().amg_hip_profile_fine_sweep(self._h, n_launches, C.byref(a), C.byref(b)))
         name = C.create_string_buffer(256)
-        k = C.c_int32(0)
-        _chk(lib().amg_hip_fine_sweep_info(self._h, name, 256, C.byref(k)))
-        return a.value, b.value, k.value, name.value.decode()
+        k, nb = C.c_int32(0), C.c_double(0)
+        _chk(lib().amg_hip_fine_sweep_info(self._h, name, 256, C.byref(k), C.byref(nb)))
+        return a.value, b.value, k.value, name.value.decode(), nb.value
 
     def coarse_solve_kind(self):
         return {0: "band (one wave, sequential, bit-exact)", 1: "spike (partitioned, parallel)",

@@ -874,6 +874,432 @@ __global__ __launch_bounds__(256) void dict_pair_up_kernel(
   dict_prolong_tail<2>(tile, n, rs, n_h, uh_in, uh_out);
 }
 
+// ---- K-Patch: the level's whole down-leg / up-leg in ONE pass over the level ------------
+// On the big levels (0 and 1 of the 4096^2 hierarchy) every sweep streams f, x and the
+// output again, 25 B per row and sweep.  The 2+2 true-Jacobi cycle touches such a level
+// five times on the way down (sweep, sweep, residual + restriction) and three times on the
+// way up (prolongation, sweep, sweep).  These kernels do each leg in one launch (temporal
+// blocking): a workgroup owns a 2-D PATCH of the level -- PATCH_TH grid lines x PATCH_TW
+// columns of the flat index (row = line * m + column; m = the pitch of the band: 4096,
+// 2048, ...) -- loads it once with the halo the later stages need (one ring of lines and
+// columns per stage), and runs the stages LDS -> LDS with a barrier in between.  The halo
+// cells are recomputed by the neighbouring patches (same expressions, same bits):
+//   down: [sweep 1] -> sweep 2 (stored) -> residual -> restriction + first coarse sweep
+//   up:   u + P u_H (formed while loading) -> sweep 1 -> sweep 2 (stored)
+// All addressing is flat-index arithmetic: cell (line lj, column li) of a patch is row
+// (j0 + lj) m + i0 + li even when i0 + li runs past the end of a grid line (the flat-index
+// smear of the reference's coarsening), so a column offset o = dj m + di of the
+// pair table is the LDS offset dj * pitch + di.  Row arithmetic = dict_rows' (entries in
+// ascending column order, diagonal split off for Jacobi, IEEE divide), transfers =
+// dict_restrict_tail / linear_prolong_add2_kernel: the V-cycle stays bit-identical.
+// The row's structure comes from its TYPE alone: the host expands type -> code word ->
+// pairs into one table of (value, diagonal value, LDS offset) per type and slot, so a
+// cell costs one byte of matrix and no decode chain.  Interior rows share one type: the
+// table reads of a wave are broadcasts.
+constexpr int PATCH_TW = 64;                 // columns of a patch (output)
+constexpr int PATCH_TH = 42;                 // lines of a patch (output)
+constexpr int PATCH_EH = PATCH_TH + 6;       // lines held, 3 rings
+constexpr int PATCH_EC = PATCH_TW + 8;       // columns held: [-4, TW + 4)
+constexpr int PATCH_NT = 576;                // threads = 8 lines of 72 cells
+constexpr int PATCH_K = PATCH_EH * PATCH_EC / PATCH_NT;  // cells per thread (6), 8 lines apart
+constexpr int PATCH_BUF = (PATCH_EH + 2) * PATCH_EC;     // + one guard line above and below
+constexpr int PATCH_MAXTAB = 192;            // table capacity: (types + 1) x slots
+static_assert(PATCH_EH * PATCH_EC == PATCH_K * PATCH_NT && PATCH_NT % PATCH_EC == 0, "patch geometry");
+
+struct PatchJ { double a, d; };              // off-diagonal value (else +0.0), diagonal value (else +0.0)
+struct PatchR { double a; int32_t loff, ok; };  // value, LDS offset, slot in use
+
+// The PATCH_K cells one thread owns: column li of lines lj0, lj0 + 8, ...; cell k sits at LDS
+// index cell0 + k * PATCH_NT and is flat row row0 + 8 k m.  Adjacent lanes own adjacent cells
+// (conflict-free 8-byte LDS accesses, coalesced global ones).
+struct PatchCells {
+  int cell0, row0, lj0, li;
+  double f[PATCH_K];
+  uint32_t ty[PATCH_K];     // row type, clamped to the all-absent table row `ntypes`
+  bool live[PATCH_K];       // row inside the matrix
+  bool uniform;             // every cell of the wave has the type tu (then the table comes
+  uint32_t tu;              // through scalar loads instead of per-lane LDS reads)
+};
+
+// The table of ONE row type held in scalar registers (the wave-uniform fast path: in the
+// interior of a level every row has the same type).  Loaded once per workgroup through
+// scalar loads from the per-type arrays the host lays out (solver.cpp: build_patch_table):
+//   utabd: per type aj[UN] (off-diagonal values, +0.0 elsewhere), ar[UN] (values), diag
+//   utabi: per type lo[UN] (LDS offsets), jmask (slots with an off-diagonal entry), rmask
+//          (slots in use)
+template <int UN>
+struct PatchU {
+  double aj[UN], ar[UN], diag;
+  int lo[UN];
+  uint32_t jmask, rmask;
+};
+template <int UN>
+__device__ __forceinline__ void patch_load_u(PatchU<UN>& U, uint32_t tu,
+                                             const double* __restrict__ utabd,
+                                             const int32_t* __restrict__ utabi) {
+  const double* d = utabd + (size_t)tu * (2 * UN + 1);
+  const int32_t* i = utabi + (size_t)tu * (UN + 2);
+#pragma unroll
+  for (int e = 0; e < UN; ++e) {
+    U.aj[e] = d[e];
+    U.ar[e] = d[UN + e];
+    U.lo[e] = i[e];
+  }
+  U.diag = d[2 * UN];
+  U.jmask = (uint32_t)i[UN];
+  U.rmask = (uint32_t)i[UN + 1];
+}
+// Uniform-type evaluation of one cell.  at[e] = cell0 + lo[e] (per lane, computed once per
+// workgroup), koff = compile-time offset of the cell and buffer.  Slots whose value is +0.0
+// for this operation (unused, or the diagonal in a Jacobi sweep) are skipped: adding or
+// subtracting (+0.0) x leaves the accumulator's bits alone for finite x (see dict_rows), and
+// the diagonal value is the type's (0.0 + ... + d + 0.0 ... = d exactly).
+template <int UN, bool RESID>
+__device__ __forceinline__ double patch_eval_u(const double* buf, const int (&at)[UN], int cell,
+                                               int koff, const PatchU<UN>& U, double fi,
+                                               double omega) {
+  constexpr uint32_t FULL = (1u << UN) - 1u;
+  if (RESID) {
+    double acc = fi;
+    if (U.rmask == FULL) {
+#pragma unroll
+      for (int e = 0; e < UN; ++e) acc -= U.ar[e] * buf[at[e] + koff];
+    } else {
+#pragma unroll
+      for (int e = 0; e < UN; ++e)
+        if ((U.rmask >> e) & 1u) acc -= U.ar[e] * buf[at[e] + koff];
+    }
+    return acc;
+  }
+  const double xi = buf[cell + koff];
+  double acc = 0.0;
+#pragma unroll
+  for (int e = 0; e < UN; ++e)
+    if ((U.jmask >> e) & 1u) acc += U.aj[e] * buf[at[e] + koff];
+  if (U.diag == 0.0) return xi;
+  const double q = (fi - acc) / U.diag;  // smoother.hpp:136
+  return xi + omega * (q - xi);
+}
+
+// Row arithmetic of dict_rows, per-lane table entries from the LDS copy (mixed row types:
+// level boundaries).
+template <int UN, bool RESID>
+__device__ __forceinline__ double patch_eval(const double* buf, int cell, uint32_t type,
+                                             const PatchJ* tabJ, const PatchR* tabR, double fi,
+                                             double omega) {
+  const int t0 = (int)type * UN;
+  double xx[UN];
+  if (RESID) {
+    double av[UN];
+    bool ok[UN];
+#pragma unroll
+    for (int e = 0; e < UN; ++e) {
+      const PatchR r = tabR[t0 + e];
+      av[e] = r.a;
+      ok[e] = r.ok != 0;
+      xx[e] = buf[cell + r.loff];
+    }
+    double acc = fi;
+#pragma unroll
+    for (int e = 0; e < UN; ++e) {
+      double t = av[e] * xx[e];
+      t = ok[e] ? t : 0.0;
+      acc -= t;
+    }
+    return acc;
+  }
+  double aj[UN], dj[UN];
+#pragma unroll
+  for (int e = 0; e < UN; ++e) {
+    const PatchJ j = tabJ[t0 + e];
+    aj[e] = j.a; dj[e] = j.d;
+    xx[e] = buf[cell + tabR[t0 + e].loff];
+  }
+  double acc = 0.0, diag = 0.0;
+  const double xi = buf[cell];
+#pragma unroll
+  for (int e = 0; e < UN; ++e) {
+    acc += aj[e] * xx[e];
+    diag += dj[e];
+  }
+  const bool nod = diag == 0.0;
+  const double q = (fi - acc) / (nod ? 1.0 : diag);  // smoother.hpp:136
+  return nod ? xi : xi + omega * (q - xi);
+}
+
+// one stage over the region lines [l0, l1) x columns [c0, c1), IN PLACE in the workgroup's one
+// LDS buffer: every thread evaluates its PATCH_K cells into registers (branch-free, so the
+// LDS reads overlap), the workgroup meets at a barrier, then the results are written back
+// (one buffer instead of two: three workgroups fit a CU instead of one, which is what these
+// latency-bound stages need).  Cells outside the region or outside the matrix keep their
+// value; ZERO: such cells inside the region are set to 0.0 instead (the residual that the
+// restriction reads).  out (optional): rows of the patch proper also go to global memory.
+template <int UN, bool RESID, bool NT, bool ZERO>
+__device__ __forceinline__ void patch_stage(const PatchCells& pc, int m, int ntypes, double* buf,
+                                            const PatchU<UN>& U, const int (&at)[UN],
+                                            const PatchJ* tabJ, const PatchR* tabR, double omega,
+                                            int l0, int l1, int c0, int c1, double* out) {
+  const bool inc = pc.li >= c0 && pc.li < c1;
+  double res[PATCH_K];
+  bool did[PATCH_K], inr[PATCH_K];
+#pragma unroll
+  for (int k = 0; k < PATCH_K; ++k) {
+    const int lj = pc.lj0 + 8 * k;
+    inr[k] = inc && lj >= l0 && lj < l1;
+    did[k] = inr[k] && pc.live[k];
+  }
+  if (pc.uniform) {
+    // interior of the level: one row type for the whole wave; cells outside the region are
+    // evaluated with it too (their reads stay inside the guard lines) and dropped
+#pragma unroll
+    for (int k = 0; k < PATCH_K; ++k)
+      res[k] = patch_eval_u<UN, RESID>(buf, at, pc.cell0, k * PATCH_NT, U, pc.f[k], omega);
+  } else {
+#pragma unroll
+    for (int k = 0; k < PATCH_K; ++k)
+      res[k] = patch_eval<UN, RESID>(buf, pc.cell0 + k * PATCH_NT,
+                                     did[k] ? pc.ty[k] : (uint32_t)ntypes, tabJ, tabR, pc.f[k], omega);
+  }
+  __syncthreads();  // everybody has read the old values
+  const bool outc = out != nullptr && pc.li >= 0 && pc.li < PATCH_TW;
+#pragma unroll
+  for (int k = 0; k < PATCH_K; ++k) {
+    if (did[k]) buf[pc.cell0 + k * PATCH_NT] = res[k];
+    else if (ZERO && inr[k]) buf[pc.cell0 + k * PATCH_NT] = 0.0;
+    const int lj = pc.lj0 + 8 * k;
+    if (outc && did[k] && lj >= 0 && lj < PATCH_TH) {
+      double* op = out + (pc.row0 + 8 * k * m);
+      if (NT) __builtin_nontemporal_store(res[k], op);
+      else *op = res[k];
+    }
+  }
+}
+
+// PROLONG: the loaded vector is x + P uH (up-leg); else plain x.
+template <bool PROLONG>
+__device__ __forceinline__ void patch_load(PatchCells& pc, int n, int m, int j0, int i0,
+                                           const double* __restrict__ x,
+                                           const double* __restrict__ f,
+                                           const uint8_t* __restrict__ rtype, int ntypes,
+                                           const double* __restrict__ uH, int nH, double* buf) {
+  const int le = (int)threadIdx.x / PATCH_EC, col = (int)threadIdx.x - le * PATCH_EC;
+  pc.lj0 = le - 3;
+  pc.li = col - 4;
+  pc.cell0 = (le + 1) * PATCH_EC + col;  // + 1: guard line
+  const int64_t r0 = (int64_t)(j0 + pc.lj0) * m + i0 + pc.li;
+  pc.row0 = (int)(r0 < -((int64_t)1 << 30) ? -((int64_t)1 << 30) : r0);
+  uint32_t mism = 0;
+  double xv[PATCH_K];
+#pragma unroll
+  for (int k = 0; k < PATCH_K; ++k) {
+    const int64_t r64 = r0 + (int64_t)8 * k * m;
+    pc.live[k] = r64 >= 0 && r64 < (int64_t)n;
+    const int row = pc.live[k] ? (int)r64 : 0;
+    xv[k] = x[row];
+    pc.f[k] = f[row];
+    pc.ty[k] = rtype[row];
+  }
+#pragma unroll
+  for (int k = 0; k < PATCH_K; ++k) {
+    const int row = pc.row0 + 8 * k * m;
+    double x0 = pc.live[k] ? xv[k] : 0.0;
+    if (PROLONG && pc.live[k]) {  // linear_prolong_add_kernel, same guards and order
+      const int j = row >> 1;
+      double t = 0.0;
+      if (row & 1) {
+        if (j < nH) t += 1.0 * uH[j];
+      } else {
+        if (j >= 1 && j - 1 < nH) t += 0.5 * uH[j - 1];
+        if (j < nH) t += 0.5 * uH[j];
+      }
+      x0 = x0 + t;
+    }
+    buf[pc.cell0 + k * PATCH_NT] = x0;
+    const uint32_t nty = (uint32_t)ntypes;
+    pc.ty[k] = (pc.live[k] && pc.ty[k] < nty) ? pc.ty[k] : nty;  // 255 = empty row -> absent row
+    pc.f[k] = pc.live[k] ? pc.f[k] : 0.0;
+  }
+  pc.tu = (uint32_t)__builtin_amdgcn_readfirstlane((int)pc.ty[0]);
+#pragma unroll
+  for (int k = 0; k < PATCH_K; ++k) mism |= pc.ty[k] ^ pc.tu;
+  pc.uniform = __builtin_amdgcn_ballot_w64(mism != 0) == 0 && pc.tu < (uint32_t)ntypes;
+}
+
+__device__ __forceinline__ void patch_stage_tables(PatchJ* tabJ, PatchR* tabR,
+                                                   const double* __restrict__ ptab, int nent) {
+  // ptab: nent x {aJ, d, aR, loff (as double; -1e9 = unused slot)}; slots past nent: absent
+  for (int t = threadIdx.x; t < PATCH_MAXTAB; t += PATCH_NT) {
+    PatchJ j = {0.0, 0.0};
+    PatchR r = {0.0, 0, 0};
+    if (t < nent) {
+      j.a = ptab[4 * t];
+      j.d = ptab[4 * t + 1];
+      r.a = ptab[4 * t + 2];
+      const double lo = ptab[4 * t + 3];
+      r.ok = lo > -1.0e8 ? 1 : 0;
+      r.loff = r.ok ? (int)lo : 0;
+    }
+    tabJ[t] = j;
+    tabR[t] = r;
+  }
+}
+// guard lines: finite values for the reads of dropped cells
+__device__ __forceinline__ void patch_clear_guards(double* buf) {
+  for (int t = threadIdx.x; t < 2 * PATCH_EC; t += PATCH_NT)
+    buf[t < PATCH_EC ? t : PATCH_BUF - 2 * PATCH_EC + t] = 0.0;
+}
+
+// common prologue: tables, guards, the uniform type's table and the per-lane gather bases
+template <int UN>
+__device__ __forceinline__ void patch_prologue(const PatchCells& pc, double* buf, PatchJ* tabJ,
+                                               PatchR* tabR, const double* __restrict__ ptab,
+                                               int nent, const double* __restrict__ utabd,
+                                               const int32_t* __restrict__ utabi, PatchU<UN>& U,
+                                               int (&at)[UN]) {
+  patch_stage_tables(tabJ, tabR, ptab, nent);
+  patch_clear_guards(buf);
+  patch_load_u<UN>(U, pc.uniform ? pc.tu : 0u, utabd, utabi);
+#pragma unroll
+  for (int e = 0; e < UN; ++e) at[e] = pc.cell0 + U.lo[e];
+}
+
+// FIRST: the input is the level's u and both pre-sweeps run here (level 0); else the input
+// is the result of the first sweep (done by the finer level's kernel) and one sweep runs.
+template <int UN, bool FIRST, bool NT>
+__global__ __launch_bounds__(PATCH_NT) void patch_down_kernel(
+    int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
+    const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
+    int nent, int ntypes, const double* x, const double* __restrict__ f, double* u_out, double* r_out, int nH,
+    double* __restrict__ fH, const double* __restrict__ diagH, double* __restrict__ uH1,
+    double omega, int xcd_map) {
+  __shared__ double buf[PATCH_BUF];
+  __shared__ PatchJ tabJ[PATCH_MAXTAB];
+  __shared__ PatchR tabR[PATCH_MAXTAB];
+  const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
+  const int py = tile / px_count, px = tile - py * px_count;
+  const int j0 = py * PATCH_TH, i0 = px * PATCH_TW;
+  PatchCells pc;
+  PatchU<UN> U;
+  int at[UN];
+  patch_load<false>(pc, n, m, j0, i0, x, f, rtype, ntypes, nullptr, 0, buf);
+  patch_prologue<UN>(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U, at);
+  __syncthreads();
+  if (FIRST) {
+    patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, -2, PATCH_TH + 2, -2,
+                                      PATCH_TW + 3, nullptr);
+    __syncthreads();
+  }
+  patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
+                                    PATCH_TW + 2, u_out);
+  __syncthreads();
+  // residual; rows outside the matrix read as 0.0 for the restriction (ZERO)
+  patch_stage<UN, true, NT, true>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW + 1,
+                                  r_out);
+  __syncthreads();
+  const double* rsb = buf;
+  // restriction + first coarse sweep: coarse row c <-> even fine row 2c of the patch
+  for (int q = threadIdx.x; q < PATCH_TH * (PATCH_TW / 2); q += PATCH_NT) {
+    const int lj = q / (PATCH_TW / 2), cx = q - lj * (PATCH_TW / 2);
+    const int64_t i = (int64_t)(j0 + lj) * m + i0 + 2 * cx;   // fine row 2c
+    const int64_t c = i >> 1;
+    if (i >= (int64_t)n || c >= nH) continue;
+    const double* rs = rsb + (lj + 4) * PATCH_EC + 2 * cx + 4;
+    double sum = 0.0;  // dict_restrict_tail / linear_restrict_kernel, same guards and order
+    if (i < n) sum += 0.5 * rs[0];
+    if (i + 1 < n) sum += 1.0 * rs[1];
+    if (i + 2 < n) sum += 0.5 * rs[2];
+    fH[c] = sum;
+    const double xi = 0.0, acc = 0.0;  // jacobi_from_zero_kernel
+    const double d = diagH[c];
+    uH1[c] = (d == 0.0) ? xi : xi + omega * ((sum - acc) / d - xi);
+  }
+}
+
+template <int UN, bool NT>
+__global__ __launch_bounds__(PATCH_NT) void patch_up_kernel(
+    int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
+    const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
+    int nent, int ntypes, const double* x, const double* __restrict__ f, const double* __restrict__ uH, int nH,
+    double* u_out, double omega, int xcd_map) {
+  __shared__ double buf[PATCH_BUF];
+  __shared__ PatchJ tabJ[PATCH_MAXTAB];
+  __shared__ PatchR tabR[PATCH_MAXTAB];
+  const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
+  const int py = tile / px_count, px = tile - py * px_count;
+  const int j0 = py * PATCH_TH, i0 = px * PATCH_TW;
+  PatchCells pc;
+  PatchU<UN> U;
+  int at[UN];
+  patch_load<true>(pc, n, m, j0, i0, x, f, rtype, ntypes, uH, nH, buf);
+  patch_prologue<UN>(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U, at);
+  __syncthreads();
+  patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
+                                    PATCH_TW + 1, nullptr);
+  __syncthreads();
+  patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW,
+                                    u_out);
+}
+
+int patch_un(int un) { return un <= 5 ? 5 : un <= 7 ? 7 : 9; }
+bool patch_geometry_ok(int64_t n, int64_t m) {
+  return m >= 2 * PATCH_TW && (m % PATCH_TW) == 0 && n >= m && n < ((int64_t)1 << 31) - 4 * m - 64;
+}
+static unsigned patch_grid(int64_t n, int64_t m, int* px_count) {
+  const int64_t lines = (n + m - 1) / m;
+  *px_count = (int)(m / PATCH_TW);
+  return (unsigned)(((lines + PATCH_TH - 1) / PATCH_TH) * *px_count);
+}
+template <class F>
+static hipError_t patch_dispatch(int un, bool nt, F&& go) {
+  using std::integral_constant;
+  auto with_nt = [&](auto U) {
+    if (nt) go(U, integral_constant<bool, true>{});
+    else go(U, integral_constant<bool, false>{});
+  };
+  if (un <= 5) with_nt(integral_constant<int, 5>{});
+  else if (un <= 7) with_nt(integral_constant<int, 7>{});
+  else if (un <= 9) with_nt(integral_constant<int, 9>{});
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+hipError_t launch_patch_down(bool first, int64_t n, int64_t m, const PatchRef& P, const double* x,
+                             const double* f, double* u_out, double* r_out, int64_t nH, double* fH,
+                             const double* diagH, double* uH1, double omega, hipStream_t st) {
+  if (!patch_geometry_ok(n, m) || !P.rtype || !P.ptab || !P.utabd || !P.utabi || (P.ntypes + 1) * patch_un(P.un) > PATCH_MAXTAB ||
+      P.nent != P.ntypes * patch_un(P.un) || !fH || !diagH || !uH1 || !u_out || u_out == x)
+    return hipErrorInvalidValue;
+  int pxc = 0;
+  const unsigned grid = patch_grid(n, m, &pxc);
+  const int xm = (g_xcd_map && !P.nt) ? 1 : 0;
+  return patch_dispatch(P.un, P.nt != 0, [&](auto U, auto NTF) {
+    if (first)
+      hipLaunchKernelGGL((patch_down_kernel<decltype(U)::value, true, decltype(NTF)::value>), dim3(grid),
+                         dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, u_out,
+                         r_out, (int)nH, fH, diagH, uH1, omega, xm);
+    else
+      hipLaunchKernelGGL((patch_down_kernel<decltype(U)::value, false, decltype(NTF)::value>), dim3(grid),
+                         dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, u_out,
+                         r_out, (int)nH, fH, diagH, uH1, omega, xm);
+  });
+}
+hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double* x, const double* f,
+                           const double* uH, int64_t nH, double* u_out, double omega,
+                           hipStream_t st) {
+  if (!patch_geometry_ok(n, m) || !P.rtype || !P.ptab || !P.utabd || !P.utabi || (P.ntypes + 1) * patch_un(P.un) > PATCH_MAXTAB ||
+      P.nent != P.ntypes * patch_un(P.un) || !uH || !u_out || u_out == x)
+    return hipErrorInvalidValue;
+  int pxc = 0;
+  const unsigned grid = patch_grid(n, m, &pxc);
+  const int xm = (g_xcd_map && !P.nt) ? 1 : 0;
+  return patch_dispatch(P.un, P.nt != 0, [&](auto U, auto NTF) {
+    hipLaunchKernelGGL((patch_up_kernel<decltype(U)::value, decltype(NTF)::value>), dim3(grid),
+                       dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, uH,
+                       (int)nH, u_out, omega, xm);
+  });
+}
+int patch_lds_pitch() { return PATCH_EC; }
+int patch_max_entries() { return PATCH_MAXTAB; }
+
 // ---- one colour of the multicolour Gauss-Seidel sweep, dictionary-coded -----------------
 // Storage rows [p0, p0 + count) are the rows of one colour (host_setup.hpp: ColorPerm),
 // rowid[p] the dof each one updates (-1 = padding); codes are indexed by storage row,

@@ -73,6 +73,34 @@ hipError_t launch_dict_pair_down(int64_t n, const DictRef& D, int hb, const doub
 hipError_t launch_dict_pair_up(int64_t n, const DictRef& D, int hb, const double* a,
                                const double* f, double* u_out, double omega, int64_t n_h,
                                const double* uh_in, double* uh_out, hipStream_t st);
+// K-Patch (kernels.hip): a level's whole down-leg / up-leg of the 2+2 true-Jacobi cycle in
+// one launch over 2-D patches of the level (temporal blocking).  ptab: per (row type, slot)
+// {off-diagonal value or +0.0, diagonal value or +0.0, value, LDS offset dj * pitch + di or
+// -1e9 for an unused slot} as 4 doubles, `un` slots per type (patch_un(longest row)),
+// nent = ntypes * un; m = pitch of the band (line length of the flat index).
+struct PatchRef {
+  const uint8_t* rtype = nullptr;
+  const double* ptab = nullptr;
+  // the same table per type for the wave-uniform path (scalar loads): utabd = per type
+  // {aJ[un], value[un], diagonal}, utabi = per type {LDS offset[un], mask of off-diagonal
+  // slots, mask of slots in use}
+  const double* utabd = nullptr;
+  const int32_t* utabi = nullptr;
+  int nent = 0, ntypes = 0, un = 0, nt = 0;
+};
+bool patch_geometry_ok(int64_t n, int64_t m);
+int patch_un(int longest_row);
+int patch_lds_pitch();
+int patch_max_entries();
+// first: both pre-sweeps (x = u) else the second only (x = result of the first sweep);
+// u_out = smoothed level vector (never x), r_out optional, f_H / uH1 as launch_dict_resid_restrict
+hipError_t launch_patch_down(bool first, int64_t n, int64_t m, const PatchRef& P, const double* x,
+                             const double* f, double* u_out, double* r_out, int64_t nH, double* fH,
+                             const double* diagH, double* uH1, double omega, hipStream_t st);
+// u_out = two Jacobi sweeps of (x + P uH); u_out must not be x
+hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double* x, const double* f,
+                           const double* uH, int64_t nH, double* u_out, double omega,
+                           hipStream_t st);
 // uh_out = uh_in + P uH for the linear interpolation pair (16-byte aligned vectors)
 hipError_t launch_linear_prolong_to(int64_t n_h, int64_t n_H, const double* uH,
                                     const double* uh_in, double* uh_out, hipStream_t st);

@@ -188,6 +188,23 @@ struct DevMat {
   int dict_hb = 0;            // largest |column offset| of the table (half-bandwidth in rows)
   bool dict_typed = false;    // second level: one byte per row into a table of code words
   DevMem dcodes, doff, dval, drtype, drwords;
+  // K-Patch (temporal blocking): per (row type, slot) table, pitch of the band
+  bool patch = false;
+  int64_t patch_m = 0;
+  int patch_un = 0, patch_ntypes = 0;
+  DevMem patch_tab, patch_utabd, patch_utabi;
+  PatchRef patch_ref() const {
+    PatchRef P;
+    P.rtype = drtype.as<uint8_t>();
+    P.ptab = patch_tab.as<double>();
+    P.utabd = patch_utabd.as<double>();
+    P.utabi = patch_utabi.as<int32_t>();
+    P.ntypes = patch_ntypes;
+    P.un = patch_un;
+    P.nent = patch_ntypes * patch_un;
+    P.nt = dict_nt;
+    return P;
+  }
   DictRef dict_ref() const {
     DictRef D;
     D.words = dict_words; D.wmax = dict_wmax; D.nt = dict_nt; D.ntab = dict_ntab;
@@ -229,6 +246,56 @@ Sparse without_exact_zeros(const Sparse& M) {
 }
 
 hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift, bool allow16);
+
+// K-Patch table of a dictionary-coded, row-typed matrix: finds the pitch m of the band (every
+// column offset must be dj * m + di with dj, di in {-1, 0, 1}: the 5-point level and the
+// 9-point Galerkin levels of a 2-D grid) and expands type -> code word -> pairs into
+// {off-diagonal value, diagonal value, value, LDS offset} per (type, slot).
+bool build_patch_table(const DictMat& T, int64_t n, int64_t* m_out, int* un_out, int* ntypes_out,
+                       std::vector<double>* tab) {
+  if (T.rtype.empty() || T.max_width > 9 || T.doff.empty()) return false;
+  int64_t omax = 0;
+  for (int32_t o : T.doff) omax = std::max<int64_t>(omax, o < 0 ? -(int64_t)o : o);
+  int ntypes = 0;
+  for (int t = 0; t < 255; ++t) {  // used types are numbered from 0; unused words are all 0xFF
+    bool used = false;
+    for (int k = 0; k < T.words; ++k) used = used || T.rwords[(size_t)t * T.words + k] != ~(uint64_t)0;
+    if (used) ntypes = t + 1;
+  }
+  const int un = patch_un(T.max_width);
+  if (ntypes < 1 || (ntypes + 1) * un > patch_max_entries()) return false;
+  const int pitch = patch_lds_pitch();
+  for (int64_t m : {omax, omax - 1}) {
+    if (!patch_geometry_ok(n, m)) continue;
+    bool ok = true;
+    std::vector<double> out((size_t)ntypes * un * 4, 0.0);
+    for (int t = 0; t < ntypes && ok; ++t)
+      for (int e = 0; e < un; ++e) {
+        double* q = &out[((size_t)t * un + e) * 4];
+        const int code = e < 8 * T.words ? (int)((T.rwords[(size_t)t * T.words + e / 8] >> (8 * (e % 8))) & 0xFF) : 0xFF;
+        if (code == 0xFF) { q[3] = -1.0e9; continue; }
+        if (code >= (int)T.doff.size()) { ok = false; break; }
+        const int64_t o = T.doff[code];
+        const double v = T.dval[code];
+        int64_t dj = 0;
+        if (o > m / 2) dj = 1;
+        else if (o < -(m / 2)) dj = -1;
+        const int64_t di = o - dj * m;
+        if (di < -1 || di > 1) { ok = false; break; }
+        q[0] = o == 0 ? 0.0 : v;
+        q[1] = o == 0 ? v : 0.0;
+        q[2] = v;
+        q[3] = (double)(dj * pitch + di);
+      }
+    if (!ok) continue;
+    *m_out = m;
+    *un_out = un;
+    *ntypes_out = ntypes;
+    tab->swap(out);
+    return true;
+  }
+  return false;
+}
 
 hipError_t upload_mat_pruned(const Sparse& M, int layout, bool prune, DevMat* D,
                              int64_t diag_shift = 0) {
@@ -278,7 +345,40 @@ hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift
         if ((e = upload(D->dcodes, T.codes.data(), T.codes.size())) != hipSuccess) return e;
       }
       if ((e = upload(D->doff, T.doff.data(), T.doff.size())) != hipSuccess) return e;
-      return upload(D->dval, T.dval.data(), T.dval.size());
+      if ((e = upload(D->dval, T.dval.data(), T.dval.size())) != hipSuccess) return e;
+      D->patch = false;
+      if (D->dict_typed && diag_shift == 0) {
+        std::vector<double> tab;
+        if (build_patch_table(T, M.n_outer, &D->patch_m, &D->patch_un, &D->patch_ntypes, &tab)) {
+          if ((e = upload(D->patch_tab, tab.data(), tab.size())) != hipSuccess) return e;
+          // per-type form for the wave-uniform path (+ the all-absent type `ntypes`)
+          const int un = D->patch_un, nty = D->patch_ntypes;
+          std::vector<double> ud((size_t)(nty + 1) * (2 * un + 1), 0.0);
+          std::vector<int32_t> ui((size_t)(nty + 1) * (un + 2), 0);
+          for (int t = 0; t < nty; ++t) {
+            double diag = 0.0;
+            uint32_t jm = 0, rm = 0;
+            for (int k = 0; k < un; ++k) {
+              const double* q = &tab[((size_t)t * un + k) * 4];
+              const bool used = q[3] > -1.0e8;
+              ud[(size_t)t * (2 * un + 1) + k] = q[0];
+              ud[(size_t)t * (2 * un + 1) + un + k] = q[2];
+              diag += q[1];  // dict_rows' order: +0.0 except the diagonal slot
+              ui[(size_t)t * (un + 2) + k] = used ? (int32_t)q[3] : 0;
+              // slots whose Jacobi value is +0.0 (unused, diagonal, pruned) add nothing
+              if (used && q[0] != 0.0) jm |= 1u << k;
+              if (used) rm |= 1u << k;
+            }
+            ud[(size_t)t * (2 * un + 1) + 2 * un] = diag;
+            ui[(size_t)t * (un + 2) + un] = (int32_t)jm;
+            ui[(size_t)t * (un + 2) + un + 1] = (int32_t)rm;
+          }
+          if ((e = upload(D->patch_utabd, ud.data(), ud.size())) != hipSuccess) return e;
+          if ((e = upload(D->patch_utabi, ui.data(), ui.size())) != hipSuccess) return e;
+          D->patch = true;
+        }
+      }
+      return hipSuccess;
     }
     if (layout == AMG_HIP_LAYOUT_DICT) layout = AMG_HIP_LAYOUT_SELL;
   }
@@ -558,9 +658,25 @@ bool fuses_resid_restrict(const amg_hip_solver* s, int l) {
   // true Jacobi: the kernel also does the first coarse sweep and needs the coarse diagonal
   return !jacobi_fuses_zero(s) || s->lv[l + 1].diag.p != nullptr;
 }
+// K-Patch: the whole down-leg / up-leg of a big level in one launch each (kernels.hip).
+// Levels 0 .. k of a 2+2 true-Jacobi cycle whose matrices are row-typed dictionaries with a
+// 2-D band (the finer level's kernel hands the first sweep of the next one over).
+int64_t g_patch_min_rows = (int64_t)1 << 20;
+bool patch_level_ok(const amg_hip_solver* s, int l) {
+  if (l < 0 || l + 2 >= (int)s->lv.size()) return false;  // needs a smoothed coarser level
+  const Level& L = s->lv[l];
+  const DevMat& A = L.A_rows;
+  if (!(jacobi_fuses_zero(s) && !s->opt.fuse_prolong && s->opt.smoother_iters == 2 && L.symmetric &&
+        A.dict && A.dict_shift == 0 && A.patch && L.linear && s->opt.stencil_transfers &&
+        L.n >= g_patch_min_rows && s->lv[l + 1].diag.p != nullptr))
+    return false;
+  return l == 0 || patch_level_ok(s, l - 1);
+}
+
 // up: last post-smoothing sweep of level l+1 + prolongation into level l
 bool fuses_jacobi_prolong(const amg_hip_solver* s, int l) {
   if (l + 2 >= (int)s->lv.size()) return false;  // the coarsest level is solved, not smoothed
+  if (patch_level_ok(s, l)) return false;  // a patch level prolongs into itself while loading
   const Level& L = s->lv[l];
   const DevMat& AC = s->lv[l + 1].A_cols();
   return jacobi_fuses_zero(s) && !jacobi_fuses_prolong(s, l) && L.linear &&
@@ -688,6 +804,20 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
     // u with the direct solve of the level's rhs (multigrid.hpp:268-274, :287-288): unless
     // the residual is to be kept, neither has an observable effect.
     if (l == nl - 1 && nl > 1 && !s->opt.keep_residual) break;
+    if (patch_level_ok(s, l)) {  // :268 (both sweeps) + :272-282 + :268 of l+1, one launch
+      Level& L = s->lv[l];
+      Level& C = s->lv[l + 1];
+      const DevMat& A = L.A_rows;
+      const bool first = l == 0;  // l >= 1: the first sweep came from level l-1's kernel (in tmp)
+      HIP_TRY(launch_patch_down(first, L.n, A.patch_m, A.patch_ref(),
+                                first ? L.u.as<double>() : L.tmp.as<double>(), L.f.as<double>(),
+                                first ? L.tmp.as<double>() : L.u.as<double>(),
+                                s->opt.keep_residual ? L.r.as<double>() : nullptr, C.n,
+                                C.f.as<double>(), C.diag.as<double>(), C.tmp.as<double>(),
+                                s->opt.omega, st));
+      first_sweep_done = true;
+      continue;
+    }
     if (first_sweep_done && pair_level_ok(s, l)) {  // second pre-sweep + residual + restriction
       Level& L = s->lv[l];
       Level& C = s->lv[l + 1];
@@ -748,6 +878,16 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
   for (int l = nl - 2; l >= 0; --l) {                              // :291
     Level& L = s->lv[l];
     Level& C = s->lv[l + 1];
+    if (patch_level_ok(s, l)) {  // :294-296 + :300 (both sweeps), one launch
+      // level 0 rests in u (its down-leg wrote tmp); coarser patch levels end in tmp
+      const DevMat& A = L.A_rows;
+      const bool top = l == 0;
+      const double* uH = patch_level_ok(s, l + 1) ? C.tmp.as<double>() : C.u.as<double>();
+      HIP_TRY(launch_patch_up(L.n, A.patch_m, A.patch_ref(),
+                              top ? L.tmp.as<double>() : L.u.as<double>(), L.f.as<double>(), uH, C.n,
+                              top ? L.u.as<double>() : L.tmp.as<double>(), s->opt.omega, st));
+      continue;
+    }
     // the last sweep of this level also prolongs into level l-1 when that fuses
     const int into = (l >= 1 && fuses_jacobi_prolong(s, l - 1)) ? l - 1 : -1;
     if (jacobi_fuses_prolong(s, l)) {                              // :294-296 inside :300
@@ -1097,6 +1237,7 @@ void amg_hip_set_nontemporal(int32_t on) { g_nontemporal = on ? 1 : 0; }
 void amg_hip_set_xcd_mapping(int32_t on) { set_xcd_mapping(on); }
 void amg_hip_set_row_types(int32_t on) { g_row_types = on ? 1 : 0; }
 void amg_hip_set_dict_rows(int32_t rows_per_lane) { set_dict_rows_per_lane(rows_per_lane); }
+void amg_hip_set_patch_min_rows(int64_t rows) { g_patch_min_rows = rows < 0 ? INT64_MAX : rows; }
 
 void amg_hip_set_default_layout(int32_t layout) {
   if (layout >= AMG_HIP_LAYOUT_AUTO && layout <= AMG_HIP_LAYOUT_DICT) g_default_layout = layout;
@@ -1306,6 +1447,8 @@ amg_hip_status amg_hip_get_transfer(const amg_hip_solver* s, int32_t level, int3
 static DevMem* pick_vec(amg_hip_solver* s, int32_t level, int32_t which) {
   if (!s || level < 0 || level >= (int32_t)s->lv.size()) return nullptr;
   Level& L = s->lv[level];
+  // a coarse K-Patch level leaves its solution in the second buffer (its up-leg cannot run in place)
+  if (which == 0 && level >= 1 && !s->opt.host_only && patch_level_ok(s, level)) return &L.tmp;
   return which == 0 ? &L.u : (which == 1 ? &L.f : (which == 2 ? &L.r : nullptr));
 }
 amg_hip_status amg_hip_get_vec(amg_hip_solver* s, int32_t level, int32_t which, double* out) {
@@ -1313,7 +1456,8 @@ amg_hip_status amg_hip_get_vec(amg_hip_solver* s, int32_t level, int32_t which, 
   if (!m || !out) return fail(AMG_HIP_EINVAL, "bad level / vector selector");
   if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "host_only solver has no vectors");
   if (which == 2 && !s->opt.keep_residual &&
-      (fuses_resid_restrict(s, level) || (level == (int32_t)s->lv.size() - 1 && level > 0)))
+      (fuses_resid_restrict(s, level) || patch_level_ok(s, level) ||
+       (level == (int32_t)s->lv.size() - 1 && level > 0)))
     return fail(AMG_HIP_EINVAL, "the residual of this level is not kept (create the solver with "
                                 "opt.keep_residual = 1)");
   HIP_TRY(hipSetDevice(s->device));
@@ -1390,11 +1534,21 @@ amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
   const DevMat& A = L.A_cols();
   std::vector<hipEvent_t> ev(2 * (size_t)n_launches);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
-  // keep u: sweep u -> tmp only (u itself is never written)
+  // keep u: sweep u -> tmp only (u itself is never written).  With K-Patch the launch is the
+  // level's whole down-leg (2 sweeps + residual + restriction + first coarse sweep); it also
+  // rewrites f and tmp of level 1, which every V-cycle recomputes before use.
+  const bool patch = patch_level_ok(s, 0);
   for (int i = 0; i < n_launches; ++i) {
     HIP_TRY(hipEventRecord(ev[2 * i], s->stream));
-    HIP_TRY(launch_mat(CSR_JACOBI, A, L.u.as<double>(), L.f.as<double>(), L.tmp.as<double>(),
-                       s->opt.omega, s->stream));
+    if (patch) {
+      Level& C = s->lv[1];
+      HIP_TRY(launch_patch_down(true, L.n, A.patch_m, A.patch_ref(), L.u.as<double>(),
+                                L.f.as<double>(), L.tmp.as<double>(), nullptr, C.n, C.f.as<double>(),
+                                C.diag.as<double>(), C.tmp.as<double>(), s->opt.omega, s->stream));
+    } else {
+      HIP_TRY(launch_mat(CSR_JACOBI, A, L.u.as<double>(), L.f.as<double>(), L.tmp.as<double>(),
+                         s->opt.omega, s->stream));
+    }
     HIP_TRY(hipEventRecord(ev[2 * i + 1], s->stream));
   }
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1412,20 +1566,34 @@ amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
 }
 
 amg_hip_status amg_hip_fine_sweep_info(const amg_hip_solver* s, char* name, int32_t name_cap,
-                                       int32_t* sweeps_per_launch) {
+                                       int32_t* sweeps_per_launch, double* bytes_per_launch) {
   if (!s || !name || name_cap < 32) return fail(AMG_HIP_EINVAL, "bad argument");
   if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "host_only solver has no device matrices");
   const Level& L = s->lv[0];
   const DevMat& A = L.A_cols();
-  if (A.dict) {
+  int32_t lay = 0;
+  int64_t mat = 0;
+  layout_of(A, &lay, &mat);
+  int sweeps = 1;
+  // bytes one launch has to move: what it reads and writes once, not a layout it does not stream
+  double bytes = 12.0 * (double)L.A_csc.nnz() + 28.0 * (double)L.n;  // SELL / CSR: SURVEY 8(d)
+  if (A.dict && patch_level_ok(s, 0)) {
+    // row types + x + f + smoothed u per fine row; f_H, first coarse sweep, coarse diagonal
+    std::snprintf(name, (size_t)name_cap, "patch_down_kernel<%d, true, %s>", patch_un(A.patch_un),
+                  A.dict_nt ? "true" : "false");
+    sweeps = 2;
+    bytes = 25.0 * (double)L.n + 24.0 * (double)s->lv[1].n;
+  } else if (A.dict) {
     dict_kernel_name(CSR_JACOBI, A.n_rows, A.dict_ref(), L.f.p, L.tmp.p, name, (size_t)name_cap);
+    bytes = (double)mat + 24.0 * (double)L.n;  // matrix stream (1 B / row) + f + x + out
   } else if (A.sell) {
     std::snprintf(name, (size_t)name_cap, "sell_kernel<1, %s, %s>", (A.idx16 & 1) ? "true" : "false",
                   (A.idx16 & 2) ? "true" : "false");
   } else {
     std::snprintf(name, (size_t)name_cap, "csr_stage_kernel<1>");
   }
-  if (sweeps_per_launch) *sweeps_per_launch = 1;
+  if (sweeps_per_launch) *sweeps_per_launch = sweeps;
+  if (bytes_per_launch) *bytes_per_launch = bytes;
   return AMG_HIP_OK;
 }
 

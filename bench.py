@@ -116,6 +116,8 @@ def run_single(args):
     if args.no_nt:
         amg.lib().amg_hip_set_nontemporal(0)
     amg.set_dict_rows(args.dict_rows)
+    if args.patch_min_rows is not None:
+        amg.set_patch_min_rows(args.patch_min_rows)
     amg.set_row_types(not args.no_row_types)
     amg.set_xcd_mapping(not args.no_xcd_map)
     amg.set_default_layout({"auto": amg.LAYOUT_AUTO, "csr": amg.LAYOUT_CSR, "sell": amg.LAYOUT_SELL,
@@ -215,15 +217,17 @@ def fine_sweep_roofline(amg, mg, args, lay_name, mat_bytes, n0, csr_formula_byte
     writes, never from a layout it does not stream:
       sell / csr: SURVEY 8(d)'s CSR formula, 12 nnz + 28 n per sweep;
       dict:       matrix stream (1 B row type per row) + f + x + out (8 B each per row);
-      a launch that does k sweeps in one pass (temporal blocking) still has to move
-      f + x + out once, so its bytes are those of ONE sweep -- the extra sweeps are the
-      traffic it saves, and they show up in V-cycles/s, not in this fraction."""
-    avg_ms, min_ms, sweeps_per_launch, kname = mg.profile_fine_sweep(launches or args.profile_launches)
-    if lay_name == "dict":
-        must_move = mat_bytes + 24 * n0
+      K-Patch (temporal blocking: a level's down-leg in one launch) still has to move
+      x, f and the smoothed u once plus the coarse vectors it produces -- the sweeps it
+      saves are traffic it no longer causes; they show up in V-cycles/s, not in this
+      fraction.  The library reports the figure (amg_hip_fine_sweep_info)."""
+    avg_ms, min_ms, sweeps_per_launch, kname, must_move = mg.profile_fine_sweep(launches or args.profile_launches)
+    if kname.startswith("patch_down"):
+        model = ("K-Patch down-leg of level 0 in one launch (2 Jacobi sweeps + residual + restriction + "
+                 "first coarse sweep): n*(1 B row type + x + f + smoothed u) + n_H*(f_H + u_H + coarse diagonal)")
+    elif lay_name == "dict":
         model = "n*(1 B row type + f + x + out) + tables"
     else:
-        must_move = csr_formula_bytes
         model = "12 nnz + 28 n (SURVEY 8(d) CSR formula)"
     achieved = must_move / (avg_ms * 1e-3) / 1e9
     traffic, traffic_src = (None, "not quoted: non-default kernel switches")
@@ -271,6 +275,9 @@ def main():
     ap.add_argument("--no-xcd-map", action="store_true", help="K-Dict: plain blockIdx -> tile mapping")
     ap.add_argument("--no-row-types", action="store_true", help="K-Dict: first-level coding only")
     ap.add_argument("--dict-rows", type=int, default=2, choices=[1, 2], help="K-Dict rows per lane")
+    ap.add_argument("--patch-min-rows", type=int, default=None,
+                    help="K-Patch (temporal blocking) on levels of at least this many rows "
+                         "(default 2^20; -1 = off)")
     ap.add_argument("--fast-coarse", action="store_true",
                     help="partitioned (parallel) coarse solve; then fewer levels pay off (--levels 13)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

@@ -156,6 +156,10 @@ void amg_hip_set_row_types(int32_t on);
 /* K-Dict rows per lane: 2 (default; 16-byte lane accesses) or 1.  Process-wide;
  * bit-identical results, a tuning / test switch.                                */
 void amg_hip_set_dict_rows(int32_t rows_per_lane);
+/* K-Patch (temporal blocking of the 2+2 true-Jacobi cycle: a level's down-leg and up-leg in
+ * one launch each over 2-D patches of the level) is used on levels of at least this many rows
+ * (process-wide; default 2^20; negative = never).  Bit-identical results; tests set 0.   */
+void amg_hip_set_patch_min_rows(int64_t rows);
 
 /* Number of usable HIP devices (0 when none; never fails). */
 int amg_hip_device_count(void);
@@ -286,9 +290,12 @@ amg_hip_status amg_hip_cycle_bytes(const amg_hip_solver* s, double* cycle_bytes,
 amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
                                           double* avg_ms, double* min_ms);
 /* Name of the kernel amg_hip_profile_fine_sweep times (as rocprofv3 prints it, without the
- * namespace) and the number of Jacobi sweeps over level 0 one launch of it performs.  */
+ * namespace), the number of Jacobi sweeps over level 0 one launch of it performs, and the
+ * bytes one launch has to move (what the kernel reads and writes once: SURVEY 8(d)'s CSR
+ * formula for the CSR / SELL layouts; row types + f + x + out for the dictionary-coded one;
+ * for the K-Patch down-leg additionally f_H, the first coarse sweep and the coarse diagonal). */
 amg_hip_status amg_hip_fine_sweep_info(const amg_hip_solver* s, char* name, int32_t name_cap,
-                                       int32_t* sweeps_per_launch);
+                                       int32_t* sweeps_per_launch, double* bytes_per_launch);
 
 /* ---- stand-alone plug-in operations on host arrays (run on the device) -----
  * SmootherBase::smooth(A, u, b), smoother.hpp:63-65, for the built-in kinds.

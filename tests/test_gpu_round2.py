@@ -228,3 +228,59 @@ def test_config5_512cubed_full_size(amg):
     assert np.array_equal(r1, r2)
     assert abs(float(np.dot(r1, r1)) - traj[-1]) <= 1e-11 * traj[-1]
     mg.close()
+
+
+# ---------------------------------------------------------------- K-Patch (temporal blocking)
+@pytest.fixture
+def patch_everywhere(amg):
+    amg.set_patch_min_rows(0)          # every level whose band has a 2-D pitch >= 128
+    yield
+    amg.set_patch_min_rows(1 << 20)
+
+
+@pytest.mark.parametrize("n,L,keep", [(128, 4, False), (256, 6, True), (512, 7, False), (192, 5, True)])
+def test_patch_kernels_bit_exact_against_oracle(amg, oracle, patch_everywhere, n, L, keep):
+    """K-Patch: a level's down-leg (2 sweeps + residual + restriction + first coarse sweep)
+    and up-leg (prolongation + 2 sweeps) in one launch each.  Same row arithmetic and
+    transfer expressions as the separate kernels: every level vector equals the oracle's
+    bit for bit over whole cycles (multigrid.hpp:263-305 with the true-Jacobi twin)."""
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
+    mg = amg.Multigrid(*csc(A), b, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6,
+                       keep_residual=keep, exact_coarse_solve=True)
+    name = mg.profile_fine_sweep(1)[3]
+    assert name.startswith("patch_down_kernel"), name
+    for c in range(3):
+        ref.vcycle()
+        mg.vcycle()
+        for l in range(L):
+            if l < L - 1 or keep:      # the coarsest level's u is the direct solve either way
+                assert np.array_equal(mg.get_soln(l), ref.get_vec(l, "u")), (c, l)
+            assert np.array_equal(mg.get_rhs(l), ref.get_vec(l, "f")), (c, l)
+            if keep:
+                assert np.array_equal(mg.get_residual(l), ref.get_vec(l, "r")), (c, l)
+    assert abs(mg.rss() - ref.rss()) <= 1e-11 * ref.rss()
+    mg.close()
+
+
+def test_patch_on_off_identical_1024(amg):
+    """A/B at 1024^2 / 12 levels without the oracle: K-Patch on levels 0-3 vs the separate
+    kernels, bitwise, including a non-zero start and a second right-hand side."""
+    n, L = 1024, 12
+    cp, ri, v = amg.laplacian(n)
+    b = amg.rhs(n)
+    rng = np.random.default_rng(5)
+    u0 = rng.standard_normal(n * n)
+    out = []
+    for rows in (0, -1):
+        amg.set_patch_min_rows(rows)
+        mg = amg.Multigrid(cp, ri, v, b, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
+        assert mg.profile_fine_sweep(1)[3].startswith("patch_down" if rows == 0 else "dict_kernel")
+        mg.set_vec(0, "u", u0)
+        mg.vcycle(3)
+        out.append((mg.get_soln(0), mg.get_soln(1), mg.get_rhs(2), mg.rss()))
+        mg.close()
+    amg.set_patch_min_rows(1 << 20)
+    for a, c in zip(out[0][:3], out[1][:3]):
+        assert np.array_equal(a, c)
+    assert out[0][3] == out[1][3]
