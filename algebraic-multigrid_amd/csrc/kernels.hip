@@ -48,6 +48,14 @@
 
 namespace amg_hip {
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding GLOBAL access of the wave (s_waitcnt vmcnt(0): prefetched operands, streamed-out
+// results); kernels whose waves talk to each other through LDS alone use this one and keep
+// their global loads and stores in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ------------------------------------------------------------------ K-CSR ----
 constexpr int CSR_BLOCK = 256;
 
@@ -1060,7 +1068,7 @@ __device__ __forceinline__ void patch_stage(const PatchCells& pc, int m, int nty
       res[k] = patch_eval<UN, RESID>(buf, pc.cell0 + k * PATCH_NT,
                                      did[k] ? pc.ty[k] : (uint32_t)ntypes, tabJ, tabR, pc.f[k], omega);
   }
-  __syncthreads();  // everybody has read the old values
+  lds_barrier();  // everybody has read the old values
   const bool outc = out != nullptr && pc.li >= 0 && pc.li < PATCH_TW;
 #pragma unroll
   for (int k = 0; k < PATCH_K; ++k) {
@@ -1103,16 +1111,16 @@ __device__ __forceinline__ void patch_load(PatchCells& pc, int n, int m, int j0,
   for (int k = 0; k < PATCH_K; ++k) {
     const int row = pc.row0 + 8 * k * m;
     double x0 = pc.live[k] ? xv[k] : 0.0;
-    if (PROLONG && pc.live[k]) {  // linear_prolong_add_kernel, same guards and order
-      const int j = row >> 1;
+    if (PROLONG) {  // linear_prolong_add_kernel, same guards and order, written with selects
+      const int j = pc.live[k] ? (row >> 1) : 0;
+      const bool odd = (row & 1) != 0;
+      const bool a_ok = pc.live[k] && !odd && j >= 1 && j - 1 < nH;
+      const bool b_ok = pc.live[k] && j < nH;
+      const double a = uH[a_ok ? j - 1 : 0], b = uH[b_ok ? j : 0];
       double t = 0.0;
-      if (row & 1) {
-        if (j < nH) t += 1.0 * uH[j];
-      } else {
-        if (j >= 1 && j - 1 < nH) t += 0.5 * uH[j - 1];
-        if (j < nH) t += 0.5 * uH[j];
-      }
-      x0 = x0 + t;
+      t = a_ok ? t + 0.5 * a : t;
+      t = b_ok ? t + (odd ? 1.0 : 0.5) * b : t;
+      x0 = pc.live[k] ? x0 + t : x0;
     }
     buf[pc.cell0 + k * PATCH_NT] = x0;
     const uint32_t nty = (uint32_t)ntypes;
@@ -1183,19 +1191,19 @@ __global__ __launch_bounds__(PATCH_NT) void patch_down_kernel(
   int at[UN];
   patch_load<false>(pc, n, m, j0, i0, x, f, rtype, ntypes, nullptr, 0, buf);
   patch_prologue<UN>(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U, at);
-  __syncthreads();
+  lds_barrier();
   if (FIRST) {
     patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, -2, PATCH_TH + 2, -2,
                                       PATCH_TW + 3, nullptr);
-    __syncthreads();
+    lds_barrier();
   }
   patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
                                     PATCH_TW + 2, u_out);
-  __syncthreads();
+  lds_barrier();
   // residual; rows outside the matrix read as 0.0 for the restriction (ZERO)
   patch_stage<UN, true, NT, true>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW + 1,
                                   r_out);
-  __syncthreads();
+  lds_barrier();
   const double* rsb = buf;
   // restriction + first coarse sweep: coarse row c <-> even fine row 2c of the patch
   for (int q = threadIdx.x; q < PATCH_TH * (PATCH_TW / 2); q += PATCH_NT) {
@@ -1232,10 +1240,10 @@ __global__ __launch_bounds__(PATCH_NT) void patch_up_kernel(
   int at[UN];
   patch_load<true>(pc, n, m, j0, i0, x, f, rtype, ntypes, uH, nH, buf);
   patch_prologue<UN>(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U, at);
-  __syncthreads();
+  lds_barrier();
   patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
                                     PATCH_TW + 1, nullptr);
-  __syncthreads();
+  lds_barrier();
   patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW,
                                     u_out);
 }
@@ -1800,6 +1808,274 @@ hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, 
     case 1024: return launch_gs_lex_b<1024>(S, b, u, mode, omega, st);
   }
   return hipErrorInvalidValue;
+}
+
+// --------------------------------------------------------------- K-GS-scan ---
+// Lexicographic Gauss-Seidel at size (smoother.hpp:148-174).  On the reference's Galerkin
+// levels row k of a forward sweep needs the NEW values of k-1 (the flat-index chain, SURVEY
+// F9) and of rows at least g = m-1 back (the previous grid line); everything else is old.
+// Inside a chunk of C <= g consecutive rows only the chain is unresolved, and it is a
+// first-order linear recurrence
+//     u_k = c_k + q_k u_{k-1},   c_k = (b_k - S_new - S_old) / a_kk,   q_k = -a_{k,k-1} / a_kk
+// (SOR: c, q blended with omega and the old u_k) that a parallel affine scan solves in
+// log C steps: (q, c) o (Q, C) = (q Q, c + q C).  ONE workgroup of 1024 threads walks the
+// level chunk by chunk: S_old (terms of rows not yet swept) is formed one chunk ahead from
+// global memory, S_new from an LDS ring of the last g + C new values, wave-level scan with
+// DPP shuffles, wave totals combined through LDS.  Same sweep, different rounding order
+// (|q| ~ 0.13-0.23: errors do not grow): agrees with the sequential sweep to ~1e-13, which
+// is why the exact dependency-scheduled kernel stays the default on small problems and
+// under opt.exact_gs.  The backward sweep is the same walk from the last row with the
+// roles of lower and upper entries swapped.
+//   mode 0: SparseGaussSeidel update (rows without diagonal keep their value)
+//   mode 1: AMG::Jacobi (forward GS)      mode 2: SOR with omega
+struct ScanEntry { double v; int32_t off; int32_t pad; };
+// row structure of a dictionary-coded row: code words from the row type or the per-row codes
+template <int WORDS>
+__device__ __forceinline__ void scan_row_words(uint64_t (&cw)[2], int k, const uint64_t* __restrict__ codes,
+                                               const uint8_t* __restrict__ rtype, const uint64_t* wtab) {
+  cw[0] = cw[1] = ~(uint64_t)0;
+  if (rtype) {
+    const uint32_t ty = rtype[k];
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) cw[w] = wtab[ty * WORDS + w];
+  } else {
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) cw[w] = codes[(int64_t)k * WORDS + w];
+  }
+}
+__device__ __forceinline__ void scan_stage_tables(ScanEntry* tab, uint64_t* wtab, int words,
+                                                  const uint8_t* rtype, const uint64_t* __restrict__ rwords,
+                                                  const int32_t* __restrict__ doff,
+                                                  const double* __restrict__ dval, int ntab) {
+  const int t = threadIdx.x;
+  if (t < 256) {
+    ScanEntry e;
+    e.v = t < ntab ? dval[t] : 0.0;
+    e.off = t < ntab ? doff[t] : 0;
+    e.pad = 0;
+    tab[t] = e;
+    if (rtype)
+      for (int k = 0; k < words; ++k) wtab[t * words + k] = rwords[t * words + k];
+  }
+}
+// Pre-pass, parallel over the whole level: the part of every row sum that a sweep takes from
+// rows it has not reached yet (forward: columns above the diagonal, backward: below) -- old
+// values, known before the sweep starts.  s_old[k] = sum in ascending column order.
+template <int WORDS, int UN>
+__global__ __launch_bounds__(256) void gs_scan_prep_kernel(
+    int n, const uint64_t* __restrict__ codes, const uint8_t* __restrict__ rtype,
+    const uint64_t* __restrict__ rwords, const int32_t* __restrict__ doff,
+    const double* __restrict__ dval, int ntab, const double* __restrict__ u, int backward,
+    double* __restrict__ s_old) {
+  __shared__ ScanEntry tab[256];
+  __shared__ uint64_t wtab[256 * WORDS];
+  scan_stage_tables(tab, wtab, WORDS, rtype, rwords, doff, dval, ntab);
+  __syncthreads();
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  uint64_t cw[2];
+  scan_row_words<WORDS>(cw, k, codes, rtype, wtab);
+  double uv[UN], vv[UN];
+  bool side[UN];
+#pragma unroll
+  for (int e = 0; e < UN; ++e) {
+    const uint32_t code = (uint32_t)(cw[e >> 3] >> (8 * (e & 7))) & 0xFFu;
+    const ScanEntry en = tab[code == 0xFFu ? 0 : code];
+    side[e] = code != 0xFFu && (backward ? en.off < 0 : en.off > 0);
+    vv[e] = en.v;
+    uv[e] = u[side[e] ? k + en.off : k];
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int e = 0; e < UN; ++e) s = side[e] ? s + vv[e] * uv[e] : s;
+  s_old[k] = s;
+}
+
+// wave-level inclusive scan of affine maps with DPP row shifts / broadcasts (no LDS crossbar
+// round trips): after it lane i holds the composition of lanes 0..i
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double ident, double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROWMASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROWMASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ void affine_step(double& Q, double& Cc) {
+  const double Qp = dpp_f64<CTRL, ROWMASK>(1.0, Q), Cp = dpp_f64<CTRL, ROWMASK>(0.0, Cc);
+  Cc = Cc + Q * Cp;   // (q, c) o (Qp, Cp): lanes without a source see the identity (1, 0)
+  Q = Q * Qp;
+}
+__device__ __forceinline__ void affine_scan_wave(double& Q, double& Cc) {
+  affine_step<0x111, 0xF>(Q, Cc);  // row_shr:1
+  affine_step<0x112, 0xF>(Q, Cc);  // row_shr:2
+  affine_step<0x114, 0xF>(Q, Cc);  // row_shr:4
+  affine_step<0x118, 0xF>(Q, Cc);  // row_shr:8
+  affine_step<0x142, 0xA>(Q, Cc);  // row_bcast:15 into rows 1 and 3
+  affine_step<0x143, 0xC>(Q, Cc);  // row_bcast:31 into rows 2 and 3
+}
+
+template <int WORDS, int UN>
+__global__ __launch_bounds__(1024) void gs_scan_kernel(
+    int n, const uint64_t* __restrict__ codes, const uint8_t* __restrict__ rtype,
+    const uint64_t* __restrict__ rwords, const int32_t* __restrict__ doff,
+    const double* __restrict__ dval, int ntab, const double* __restrict__ b, double* u,
+    const double* __restrict__ s_old, int backward, int mode, double omega, int C, int ringmask) {
+  extern __shared__ double ring[];           // new values of the last rows, by row & ringmask
+  __shared__ ScanEntry tab[256];
+  __shared__ uint64_t wtab[256 * WORDS];
+  __shared__ double totQ[16], totC[16], carry_in[16];
+  __shared__ double last_u;                  // new value of the row before this chunk
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  scan_stage_tables(tab, wtab, WORDS, rtype, rwords, doff, dval, ntab);
+  for (int i = t; i <= ringmask; i += 1024) ring[i] = 0.0;
+  if (t == 0) last_u = 0.0;
+  __syncthreads();
+  const int nchunks = (n + C - 1) / C;
+  const int chain = backward ? 1 : -1;       // offset of the chained neighbour
+  // operands of one row, fetched two chunks ahead
+  // (only global loads here, nothing that depends on them: the type -> code word lookup
+  // happens when the row is used, two chunks later)
+  struct Row {
+    uint64_t cw[2];
+    uint32_t ty;
+    double bk, uk, so;
+    int k;
+    bool live;
+  };
+  auto fetch = [&](int chunk, Row& r) {
+    const int idx = chunk * C + t;
+    r.live = chunk < nchunks && t < C && idx < n;
+    r.k = backward ? n - 1 - idx : idx;
+    r.cw[0] = r.cw[1] = ~(uint64_t)0;
+    r.ty = 255;
+    r.bk = r.uk = r.so = 0.0;
+    if (!r.live) return;
+    if (rtype) {
+      r.ty = rtype[r.k];
+    } else {
+#pragma unroll
+      for (int w = 0; w < WORDS; ++w) r.cw[w] = codes[(int64_t)r.k * WORDS + w];
+    }
+    r.bk = b[r.k];
+    r.uk = u[r.k];
+    r.so = s_old[r.k];
+  };
+  // waves beyond the chunk length only take part in the barriers
+  const bool active = wave * 64 < C;
+  const int nwaves = (C + 63) >> 6;
+  Row cur, nx1, nx2;
+  cur.live = nx1.live = nx2.live = false;
+  if (active) {
+    fetch(0, cur);
+    fetch(1, nx1);
+  }
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    double Q = 1.0, Cc = 0.0;
+    if (active) {
+      fetch(chunk + 2, nx2);  // in flight during two scans
+      // (q, c) of this row from the new values of earlier chunks
+      double q = 0.0, c = 0.0;
+      if (cur.live) {
+        if (rtype) {
+#pragma unroll
+          for (int w = 0; w < WORDS; ++w) cur.cw[w] = wtab[cur.ty * WORDS + w];
+        }
+        double s_new = 0.0, diag = 0.0, achain = 0.0;
+#pragma unroll
+        for (int e = 0; e < UN; ++e) {
+          const uint32_t code = (uint32_t)(cur.cw[e >> 3] >> (8 * (e & 7))) & 0xFFu;
+          const ScanEntry en = tab[code == 0xFFu ? 0 : code];
+          const bool used = code != 0xFFu;
+          const bool isdiag = used && en.off == 0;
+          const bool ischain = used && en.off == chain;
+          const bool new_side = used && !ischain && (backward ? en.off > 0 : en.off < 0);
+          diag = isdiag ? en.v : diag;
+          achain = ischain ? en.v : achain;
+          const double rv = ring[(cur.k + (new_side ? en.off : 0)) & ringmask];
+          s_new = new_side ? s_new + en.v * rv : s_new;
+        }
+        const double rsum = s_new + cur.so;
+        if (mode == 0 && diag == 0.0) {       // smoother.hpp:134-137: row left alone
+          c = cur.uk;
+          q = 0.0;
+        } else {
+          const double g = (cur.bk - rsum) / diag;
+          const double qq = -achain / diag;
+          if (mode == 2) {                    // u_k + omega (g - u_k), smoother.hpp:360-362
+            c = cur.uk + omega * (g - cur.uk);
+            q = omega * qq;
+          } else {
+            c = g;
+            q = qq;
+          }
+        }
+      }
+      // inclusive affine scan inside the wave: (Q, Cc) maps the value before the wave's
+      // first row to this row's value
+      Q = q;
+      Cc = c;
+      affine_scan_wave(Q, Cc);
+      if (lane == 63) {
+        totQ[wave] = Q;
+        totC[wave] = Cc;
+      }
+    }
+    lds_barrier();
+    // second level: wave 0 turns the wave totals into the value BEFORE each wave's first row
+    if (wave == 0) {
+      double tq = lane < nwaves ? totQ[lane & 15] : 1.0, tc = lane < nwaves ? totC[lane & 15] : 0.0;
+      affine_scan_wave(tq, tc);
+      const double after = tc + tq * last_u;     // value of wave `lane`'s last row
+      if (lane < 15) carry_in[lane + 1] = after;
+      if (lane == 0) carry_in[0] = last_u;
+    }
+    lds_barrier();
+    if (active) {
+      const double unew = Cc + Q * carry_in[wave];
+      if (cur.live) {
+        ring[cur.k & ringmask] = unew;
+        u[cur.k] = unew;
+      }
+      const int last_t = (chunk * C + C <= n ? C : n - chunk * C) - 1;
+      if (t == last_t) last_u = unew;
+    }
+    lds_barrier();                             // ring and last_u are ready for the next chunk
+    cur = nx1;
+    nx1 = nx2;
+  }
+}
+
+template <int WORDS, int UN>
+static hipError_t launch_gs_scan_wu(int64_t n, const DictRef& D, const double* b, double* u,
+                                    double* s_old, int backward, int mode, double omega, int C,
+                                    int ring, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gs_scan_kernel<WORDS, UN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gs_scan_prep_kernel<WORDS, UN>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                     (int)n, D.codes, D.rtype, D.rwords, D.doff, D.dval, D.ntab, u, backward, s_old);
+  hipLaunchKernelGGL((gs_scan_kernel<WORDS, UN>), dim3(1), dim3(1024), (size_t)ring * 8, st, (int)n,
+                     D.codes, D.rtype, D.rwords, D.doff, D.dval, D.ntab, b, u, s_old, backward, mode,
+                     omega, C, ring - 1);
+  return hipGetLastError();
+}
+// C: rows per chunk (<= 1024 and <= the distance of the nearest non-chain dependency);
+// ring: power of two >= largest dependency distance + C + 1, at most 16384 doubles
+hipError_t launch_gs_scan(int64_t n, const DictRef& D, const double* b, double* u, double* s_old,
+                          bool backward, int mode, double omega, int C, int ring, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (!dict_args_ok(n, D.words, D.wmax, D.ntab) || C < 1 || C > 1024 || ring < 2 || ring > 16384 ||
+      (ring & (ring - 1)) || !s_old)
+    return hipErrorInvalidValue;
+  hipError_t r = hipSuccess;
+  (void)dict_dispatch_wu(D.words, D.wmax, [&](auto W, auto U) {
+    r = launch_gs_scan_wu<decltype(W)::value, decltype(U)::value>(n, D, b, u, s_old, backward ? 1 : 0,
+                                                                  mode, omega, C, ring, st);
+  });
+  return r;
 }
 
 // ------------------------------------------------------- K-Halo (in-graph comm) ---

@@ -174,6 +174,14 @@ struct LexDev {  // device copy of a LexSchedule
 hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, double omega,
                          hipStream_t st);
 
+// Line-scan form of the lexicographic sweeps on a dictionary-coded matrix (K-GS-scan):
+// chunks of C rows, the in-chunk chain u_k = c_k + q_k u_{k-1} solved by an affine scan.
+// mode 0 SpGS update, 1 reference "Jacobi" (forward GS), 2 SOR.  ring: power of two.
+// s_old: scratch of n doubles (the sums over rows the sweep has not reached, formed by a
+// parallel pre-pass).
+hipError_t launch_gs_scan(int64_t n, const DictRef& D, const double* b, double* u, double* s_old,
+                          bool backward, int mode, double omega, int C, int ring, hipStream_t st);
+
 // m: lanes taking part (power of two > half-bandwidth, 4..64); sched_f/sched_b:
 // per-(step, lane) L operands (host_setup: band_schedule); y: scratch, n doubles
 hipError_t launch_band_solve(int64_t n, int m, const double* sched_f, const double* sched_b,

@@ -188,6 +188,9 @@ struct DevMat {
   int dict_hb = 0;            // largest |column offset| of the table (half-bandwidth in rows)
   bool dict_typed = false;    // second level: one byte per row into a table of code words
   DevMem dcodes, doff, dval, drtype, drwords;
+  // K-GS-scan: nearest dependency of a lexicographic sweep other than the chained neighbour
+  // (min |offset| over the pairs with |offset| >= 2) and the farthest one; 0 = not usable
+  int64_t scan_gap = 0, scan_far = 0;
   // K-Patch (temporal blocking): per (row type, slot) table, pitch of the band
   bool patch = false;
   int64_t patch_m = 0;
@@ -346,6 +349,17 @@ hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift
       }
       if ((e = upload(D->doff, T.doff.data(), T.doff.size())) != hipSuccess) return e;
       if ((e = upload(D->dval, T.dval.data(), T.dval.size())) != hipSuccess) return e;
+      D->scan_gap = D->scan_far = 0;
+      if (diag_shift == 0) {
+        int64_t gap = INT64_MAX, far = 1;
+        for (int32_t o : T.doff) {
+          const int64_t a = o < 0 ? -(int64_t)o : o;
+          if (a >= 2) gap = std::min(gap, a);
+          far = std::max(far, a);
+        }
+        D->scan_gap = gap == INT64_MAX ? (int64_t)1 << 20 : gap;
+        D->scan_far = far;
+      }
       D->patch = false;
       if (D->dict_typed && diag_shift == 0) {
         std::vector<double> tab;
@@ -480,6 +494,8 @@ struct CoarseOnDev {
   DevMem sf, sb, d;                  // BAND / WIDE schedules
   std::unique_ptr<SpikeOnDev> spike;
 };
+// level-0 rows from which the lexicographic smoothers take the line-scan form by default
+constexpr int64_t GS_SCAN_MIN_ROWS = 65536;
 // serial substitution costs ~44 ns per row and pass; from this size on the partitioned
 // solve is the default (opt.exact_coarse_solve keeps the bit-exact one)
 constexpr int64_t COARSE_SPIKE_MIN_ROWS = 4096;
@@ -593,6 +609,7 @@ struct Level {
   DevCsr P_rows, R_rows;   // CSR(P), CSR(R)
   // exact lexicographic schedules
   std::unique_ptr<LexOnDev> lex_fwd, lex_bwd;
+  int scan_C = 0, scan_ring = 0;  // > 0: the lexicographic sweeps run as K-GS-scan
   // multicolour: colour-permuted SELL-64 copy + dof of every storage row
   std::vector<int32_t> color;
   int32_t n_colors = 0;
@@ -707,6 +724,14 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
   switch (s->opt.smoother) {
     case AMG_HIP_SM_SPGS:
       for (int it = 0; it < iters; ++it) {
+        if (L.scan_C > 0) {  // line-scan form (kernels.hip: K-GS-scan)
+          const DictRef D = L.A_rows.dict_ref();
+          HIP_TRY(launch_gs_scan(L.n, D, L.f.as<double>(), L.u.as<double>(), L.tmp.as<double>(), false, 0,
+                                 1.0, L.scan_C, L.scan_ring, st));
+          HIP_TRY(launch_gs_scan(L.n, D, L.f.as<double>(), L.u.as<double>(), L.tmp.as<double>(), true, 0,
+                                 1.0, L.scan_C, L.scan_ring, st));
+          continue;
+        }
         HIP_TRY(launch_gs_lex(L.lex_fwd->d, L.f.as<double>(), L.u.as<double>(), 0, 1.0, st));
         HIP_TRY(launch_gs_lex(L.lex_bwd->d, L.f.as<double>(), L.u.as<double>(), 0, 1.0, st));
       }
@@ -714,9 +739,15 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
     case AMG_HIP_SM_REF_JACOBI:
     case AMG_HIP_SM_SOR: {
       const int mode = s->opt.smoother == AMG_HIP_SM_SOR ? 2 : 1;
-      for (int it = 0; it < iters; ++it)
+      for (int it = 0; it < iters; ++it) {
+        if (L.scan_C > 0) {
+          HIP_TRY(launch_gs_scan(L.n, L.A_rows.dict_ref(), L.f.as<double>(), L.u.as<double>(),
+                                 L.tmp.as<double>(), false, mode, s->opt.omega, L.scan_C, L.scan_ring, st));
+          continue;
+        }
         HIP_TRY(launch_gs_lex(L.lex_fwd->d, L.f.as<double>(), L.u.as<double>(), mode,
                               s->opt.omega, st));
+      }
       return AMG_HIP_OK;
     }
     case AMG_HIP_SM_JACOBI: {
@@ -1076,7 +1107,24 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     HIP_TRY(hipMemset(L.r.p, 0, sizeof(double) * L.n));
     timer.lap(T_ENC);
     // smoother-specific structures
-    if (s->opt.smoother == AMG_HIP_SM_SPGS) {
+    // Lexicographic sweeps at size: the line-scan form, unless opt.exact_gs or a small
+    // problem (the exact dependency-scheduled kernel is bit-exact and fast enough there)
+    if (s->opt.smoother <= AMG_HIP_SM_SOR && !s->opt.exact_gs && s->lv[0].n > GS_SCAN_MIN_ROWS &&
+        L.symmetric) {
+      const DevMat& A = L.A_rows;
+      if (A.dict && A.dict_shift == 0 && A.scan_gap >= 32) {
+        int ring = 128;
+        const int C = (int)std::min<int64_t>(A.scan_gap, 1024);
+        while (ring < A.scan_far + C + 1 && ring <= 16384) ring *= 2;
+        if (ring <= 16384) {
+          L.scan_C = C;
+          L.scan_ring = ring;
+        }
+      }
+    }
+    if (L.scan_C > 0) {
+      // no schedule needed
+    } else if (s->opt.smoother == AMG_HIP_SM_SPGS) {
       LexSchedule F, B;
       std::string e = build_lex_schedule(L.A_csc, false, 16, &F);
       if (e.empty()) e = build_lex_schedule(L.A_csc, true, 16, &B);

@@ -284,3 +284,62 @@ def test_patch_on_off_identical_1024(amg):
     for a, c in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(a, c)
     assert out[0][3] == out[1][3]
+
+
+# ---------------------------------------------------------------- K-GS-scan (SpGS at size)
+def test_spgs_at_size_config2_within_1e10_and_faster_than_cpu(amg, oracle):
+    """BASELINE config 2 with the reference's DEFAULT smoother (SparseGaussSeidel(), exact
+    lexicographic order, smoother.hpp:148-174) at full size.  From 65536 fine rows on the
+    sweeps run as K-GS-scan (same sweep, the in-line chain solved by an affine scan):
+    solution and rss within 1e-10 of the oracle after every cycle, and -- VERDICT r1 weak #6
+    -- the V-cycle must beat the CPU oracle's (it was 3x slower)."""
+    import time
+    n, L = 1024, 6
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    ref = oracle.Multigrid(A, b, L)
+    mg = amg.Multigrid(*csc(A), b, L, exact_coarse_solve=True)
+    for c in range(3):
+        ref.vcycle()
+        mg.vcycle()
+        u, ur = mg.get_soln(0), ref.get_vec(0, "u")
+        assert np.linalg.norm(u - ur) <= 1e-10 * np.linalg.norm(ur), c
+        assert abs(mg.rss() - ref.rss()) <= 1e-10 * ref.rss(), c
+    for l in range(1, L):
+        assert np.linalg.norm(mg.get_soln(l) - ref.get_vec(l, "u")) <= 1e-9 * np.linalg.norm(ref.get_vec(l, "u"))
+    cpu = min(ref.time_vcycles(1) for _ in range(2))
+    mg.sync()
+    t0 = time.perf_counter()
+    mg.vcycle(3)
+    mg.sync()
+    gpu = (time.perf_counter() - t0) / 3
+    print(f"config 2, SparseGaussSeidel(): GPU {gpu * 1e3:.1f} ms / V-cycle, CPU oracle {cpu * 1e3:.1f} ms")
+    assert gpu < cpu
+    mg.close()
+
+
+@pytest.mark.parametrize("kind", ["sor", "refjacobi", "spgs2"])
+def test_scan_form_of_the_other_reference_smoothers(amg, oracle, kind):
+    """AMG::Jacobi (forward GS) and SOR through K-GS-scan, and SpGS with n_iters = 2, on a
+    grid with ragged line ends (n odd): 1e-10 against the oracle, every level."""
+    n, L = 301, 5
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    kw_o = {"sor": dict(smoother=oracle.SM_SOR, smoother_iters=2, omega=1.3),
+            "refjacobi": dict(smoother=oracle.SM_REF_JACOBI, smoother_iters=1),
+            "spgs2": dict(smoother=oracle.SM_SPGS, smoother_iters=2)}[kind]
+    kw_g = {"sor": dict(smoother=amg.SM_SOR, smoother_iters=2, omega=1.3),
+            "refjacobi": dict(smoother=amg.SM_REF_JACOBI, smoother_iters=1),
+            "spgs2": dict(smoother=amg.SM_SPGS, smoother_iters=2)}[kind]
+    ref = oracle.Multigrid(A, b, L, **kw_o)
+    mg = amg.Multigrid(*csc(A), b, L, **kw_g)
+    ex = amg.Multigrid(*csc(A), b, L, exact_gs=True, exact_coarse_solve=True, **kw_g)
+    for c in range(2):
+        ref.vcycle()
+        mg.vcycle()
+        ex.vcycle()
+    for l in range(L):
+        ur = ref.get_vec(l, "u")
+        assert np.array_equal(ex.get_soln(l), ur), (kind, l)            # exact kernel: bit for bit
+        assert np.linalg.norm(mg.get_soln(l) - ur) <= 1e-10 * np.linalg.norm(ur), (kind, l)
+    assert abs(mg.rss() - ref.rss()) <= 1e-10 * ref.rss()
+    mg.close()
+    ex.close()
