@@ -89,6 +89,8 @@ _SIGS = {
     "amg_hip_solve": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_int64, _i64p, _f64p,
                                 _i32p]),
     "amg_hip_rss": (C.c_int, [C.c_void_p, _f64p]),
+    "amg_hip_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "amg_hip_pcg": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, _i64p, _f64p]),
     "amg_hip_n_levels": (C.c_int32, [C.c_void_p]),
     "amg_hip_get_n_dofs": (C.c_int64, [C.c_void_p, C.c_int32]),
     "amg_hip_get_level_nnz": (C.c_int64, [C.c_void_p, C.c_int32]),
@@ -454,6 +456,16 @@ class Multigrid:
         out = C.c_double(0)
         _chk(lib().amg_hip_rss(self._h, C.byref(out)))
         return out.value
+
+    def apply_dev(self, v_dev, z_dev):
+        """z = M^-1 v (one V-cycle from zero); device pointers."""
+        _chk(lib().amg_hip_apply(self._h, C.c_void_p(v_dev), C.c_void_p(z_dev)))
+
+    def pcg(self, rtol=1e-10, max_iters=100):
+        """CG on A_0 x = b preconditioned with one V-cycle; returns (x, iters, relres)."""
+        it, rel = C.c_int64(0), C.c_double(0)
+        _chk(lib().amg_hip_pcg(self._h, rtol, max_iters, C.byref(it), C.byref(rel)))
+        return self.get_soln(0), it.value, rel.value
 
     def solve(self):
         """multigrid.hpp:311-337.  Returns (u, iters, converged, last_rss) and

@@ -1690,6 +1690,66 @@ hipError_t launch_sum(int64_t n, const double* x, double* out, double* scratch, 
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ K-PCG -----
+// Vector kernels of the preconditioned conjugate-gradient driver (the V-cycle as M^-1,
+// README.md:127 of the reference): deterministic two-stage dot product and the two
+// updates; the scalars alpha / beta are formed on the device from the dot products in
+// sc[], so an iteration needs no host round trip.
+__global__ __launch_bounds__(256) void dot_kernel(int64_t n, const double* __restrict__ x,
+                                                  const double* __restrict__ y,
+                                                  double* __restrict__ out) {
+  __shared__ double part[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    s += x[i] * y[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = ((part[0] + part[1]) + part[2]) + part[3];
+}
+hipError_t launch_dot(int64_t n, const double* x, const double* y, double* out, double* scratch,
+                      hipStream_t st) {
+  int64_t g = (n + 255) / 256;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(dot_kernel, dim3((unsigned)g), dim3(256), 0, st, n, x, y, scratch);
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, g, scratch, out, 0);
+  return hipGetLastError();
+}
+// alpha = num / den;  x = x + alpha p;  r = r - alpha q
+__global__ __launch_bounds__(256) void pcg_update_xr_kernel(int64_t n, const double* __restrict__ num,
+                                                            const double* __restrict__ den, double* x,
+                                                            double* r, const double* __restrict__ p,
+                                                            const double* __restrict__ q) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double alpha = *num / *den;
+  x[i] = x[i] + alpha * p[i];
+  r[i] = r[i] - alpha * q[i];
+}
+// beta = num / den;  p = z + beta p
+__global__ __launch_bounds__(256) void pcg_update_p_kernel(int64_t n, const double* __restrict__ num,
+                                                           const double* __restrict__ den, double* p,
+                                                           const double* __restrict__ z) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double beta = *num / *den;
+  p[i] = z[i] + beta * p[i];
+}
+hipError_t launch_pcg_update_xr(int64_t n, const double* num, const double* den, double* x, double* r,
+                                const double* p, const double* q, hipStream_t st) {
+  hipLaunchKernelGGL(pcg_update_xr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, num,
+                     den, x, r, p, q);
+  return hipGetLastError();
+}
+hipError_t launch_pcg_update_p(int64_t n, const double* num, const double* den, double* p,
+                               const double* z, hipStream_t st) {
+  hipLaunchKernelGGL(pcg_update_p_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, num,
+                     den, p, z);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- K-GS-lex ---
 // Exact lexicographic Gauss-Seidel (smoother.hpp:101-174) under a dependency
 // schedule built on the host (host_setup.cpp: build_lex_schedule).  ONE

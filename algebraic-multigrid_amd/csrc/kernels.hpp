@@ -133,6 +133,15 @@ hipError_t launch_add_inplace(int64_t n, const double* x, double* y, hipStream_t
 hipError_t launch_sum(int64_t n, const double* x, double* out, double* scratch, int square,
                       hipStream_t st);
 
+// K-PCG: *out = sum x_i y_i (deterministic two-stage tree; scratch: 1024 doubles), and the
+// two vector updates with alpha = *num / *den resp. beta = *num / *den formed on the device
+hipError_t launch_dot(int64_t n, const double* x, const double* y, double* out, double* scratch,
+                      hipStream_t st);
+hipError_t launch_pcg_update_xr(int64_t n, const double* num, const double* den, double* x, double* r,
+                                const double* p, const double* q, hipStream_t st);
+hipError_t launch_pcg_update_p(int64_t n, const double* num, const double* den, double* p,
+                               const double* z, hipStream_t st);
+
 // In-graph neighbour exchange (K-Halo).  All pointers are device pointers; *_at_*
 // and dst_* point into a neighbour's hipIpc-mapped arena.
 struct HaloArgs {

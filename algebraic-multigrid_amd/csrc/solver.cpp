@@ -631,6 +631,7 @@ struct amg_hip_solver {
   std::vector<Level> lv;
   CoarseOnDev coarse;  // coarsest level factor
   DevMem scratch;   // 1024 doubles + 1 result
+  DevMem pcg_x, pcg_p, pcg_q, pcg_b;  // PCG work vectors (allocated on first use)
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   bool graph_ready = false;
@@ -1432,6 +1433,114 @@ amg_hip_status amg_hip_rss(amg_hip_solver* s, double* out) {
   HIP_TRY(hipMemcpyAsync(out, sc + 1024, sizeof(double), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return AMG_HIP_OK;
+}
+
+// z = M^-1 v: one V-cycle from a zero guess on the right-hand side v (README.md:127, ref [7]
+// of the reference: "a single V-cycle used for preconditioner").  Level 0's f and u are the
+// cycle's operands, so they are parked in the PCG work vectors and put back.
+static amg_hip_status pcg_alloc(amg_hip_solver* s) {
+  const size_t bytes = sizeof(double) * (size_t)s->lv[0].n;
+  if (s->pcg_x.p) return AMG_HIP_OK;
+  HIP_TRY(s->pcg_x.alloc(bytes));
+  HIP_TRY(s->pcg_p.alloc(bytes));
+  HIP_TRY(s->pcg_q.alloc(bytes));
+  HIP_TRY(s->pcg_b.alloc(bytes));
+  return AMG_HIP_OK;
+}
+amg_hip_status amg_hip_apply(amg_hip_solver* s, const double* v_dev, double* z_dev) {
+  if (!s || !v_dev || !z_dev) return fail(AMG_HIP_EINVAL, "null argument");
+  amg_hip_status r = set_device(s);
+  if (r != AMG_HIP_OK) return r;
+  if ((r = pcg_alloc(s)) != AMG_HIP_OK) return r;
+  Level& L = s->lv[0];
+  const size_t bytes = sizeof(double) * (size_t)L.n;
+  hipStream_t st = s->stream;
+  HIP_TRY(hipMemcpyAsync(s->pcg_b.p, L.f.p, bytes, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(s->pcg_x.p, L.u.p, bytes, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(L.f.p, v_dev, bytes, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemsetAsync(L.u.p, 0, bytes, st));
+  if ((r = amg_hip_vcycles(s, 1)) != AMG_HIP_OK) return r;
+  HIP_TRY(hipMemcpyAsync(z_dev, L.u.p, bytes, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(L.f.p, s->pcg_b.p, bytes, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(L.u.p, s->pcg_x.p, bytes, hipMemcpyDeviceToDevice, st));
+  return AMG_HIP_OK;
+}
+
+// Preconditioned conjugate gradients on A_0 x = b, M^-1 = one V-cycle from zero.  During the
+// iteration level 0's f holds the residual r and level 0's u receives z = M^-1 r (no copies
+// around the cycle); x, p, q = A p live in the work vectors.  Start: x = the level-0
+// solution; on return it holds the result and f is b again.
+amg_hip_status amg_hip_pcg(amg_hip_solver* s, double rtol, int64_t max_iters, int64_t* iters,
+                           double* relres) {
+  if (!s) return fail(AMG_HIP_EINVAL, "null solver");
+  if (!(rtol >= 0) || max_iters < 0) return fail(AMG_HIP_EINVAL, "bad tolerance / iteration limit");
+  amg_hip_status st0 = set_device(s);
+  if (st0 != AMG_HIP_OK) return st0;
+  if ((st0 = pcg_alloc(s)) != AMG_HIP_OK) return st0;
+  Level& L = s->lv[0];
+  const int64_t n = L.n;
+  const size_t bytes = sizeof(double) * (size_t)n;
+  hipStream_t st = s->stream;
+  double* x = s->pcg_x.as<double>();
+  double* p = s->pcg_p.as<double>();
+  double* q = s->pcg_q.as<double>();
+  double* bsv = s->pcg_b.as<double>();
+  double* r = L.f.as<double>();   // residual lives where the cycle expects its right-hand side
+  double* z = L.u.as<double>();   // and the cycle leaves M^-1 r here
+  double* sc = s->scratch.as<double>();
+  double* part = sc;              // 1024 partials
+  double* d_rz = sc + 1030;       // device scalars: r.z, p.q, new r.z, r.r
+  double* d_pq = sc + 1031;
+  double* d_rzn = sc + 1032;
+  double* d_rr = sc + 1033;
+  double h[2];
+  // b . b
+  HIP_TRY(launch_dot(n, r, r, d_rr, part, st));
+  HIP_TRY(hipMemcpyAsync(h, d_rr, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const double bnorm = std::sqrt(h[0]);
+  HIP_TRY(hipMemcpyAsync(bsv, r, bytes, hipMemcpyDeviceToDevice, st));   // park b
+  HIP_TRY(hipMemcpyAsync(x, z, bytes, hipMemcpyDeviceToDevice, st));     // x = u_0
+  // r = b - A x (multigrid.hpp:272-274 arithmetic), in place of b
+  HIP_TRY(launch_mat(CSR_RESID, L.A_rows, x, bsv, r, 1.0, st));
+  int64_t it = 0;
+  double rel = 0.0;
+  auto finish = [&]() -> amg_hip_status {
+    HIP_TRY(hipMemcpyAsync(L.f.p, bsv, bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(L.u.p, x, bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (iters) *iters = it;
+    if (relres) *relres = rel;
+    return AMG_HIP_OK;
+  };
+  HIP_TRY(launch_dot(n, r, r, d_rr, part, st));
+  HIP_TRY(hipMemcpyAsync(h, d_rr, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  rel = bnorm > 0 ? std::sqrt(h[0]) / bnorm : std::sqrt(h[0]);
+  if (rel <= rtol || max_iters == 0) return finish();
+  // z = M^-1 r; p = z; rz = r . z
+  HIP_TRY(hipMemsetAsync(z, 0, bytes, st));
+  amg_hip_status rc = amg_hip_vcycles(s, 1);
+  if (rc != AMG_HIP_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(p, z, bytes, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(launch_dot(n, r, z, d_rz, part, st));
+  while (it < max_iters) {
+    HIP_TRY(launch_mat(CSR_SPMV, L.A_rows, p, nullptr, q, 1.0, st));     // q = A p
+    HIP_TRY(launch_dot(n, p, q, d_pq, part, st));
+    HIP_TRY(launch_pcg_update_xr(n, d_rz, d_pq, x, r, p, q, st));        // alpha = rz / pq
+    HIP_TRY(launch_dot(n, r, r, d_rr, part, st));
+    HIP_TRY(hipMemcpyAsync(h, d_rr, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    it += 1;
+    rel = bnorm > 0 ? std::sqrt(h[0]) / bnorm : std::sqrt(h[0]);
+    if (!(rel > rtol) || it >= max_iters) break;                         // NaN leaves too
+    HIP_TRY(hipMemsetAsync(z, 0, bytes, st));
+    if ((rc = amg_hip_vcycles(s, 1)) != AMG_HIP_OK) return rc;           // z = M^-1 r
+    HIP_TRY(launch_dot(n, r, z, d_rzn, part, st));
+    HIP_TRY(launch_pcg_update_p(n, d_rzn, d_rz, p, z, st));              // beta = rz_new / rz
+    HIP_TRY(hipMemcpyAsync(d_rz, d_rzn, sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
+  return finish();
 }
 
 amg_hip_status amg_hip_solve(amg_hip_solver* s, double tol, int64_t every, int64_t n_iters,

@@ -201,6 +201,8 @@ class Multigrid {
   void display_error_off() { display_error = true; }  // sic: reference multigrid.hpp:361-364
 
   amg_hip_solver* native_handle() { return handle; }
+  // false when smooth() of a user-defined (or rss-checking) smoother runs on the host
+  bool runs_on_device() const { return !custom_smoother; }
 };
 
 }  // namespace AMG

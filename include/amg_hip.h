@@ -212,6 +212,23 @@ amg_hip_status amg_hip_solve(amg_hip_solver* s, double tol, int64_t every,
                              int64_t n_iters, int64_t* iters, double* last_rss,
                              int32_t* converged);
 
+/* ---- the V-cycle as a preconditioner (README.md:127 of the reference, its ref [7]: "a
+ * single V-cycle used for preconditioner to get M^-1 v") ------------
+ * amg_hip_apply: z = M^-1 v, i.e. ONE vcycle() (multigrid.hpp:263-305) started from the
+ * zero vector with v as the level-0 right-hand side.  v_dev / z_dev are DEVICE pointers
+ * (n_dofs(0) doubles, may alias each other); enqueued on the solver's stream; the solver's
+ * own right-hand side and solution are left as they were.                             */
+amg_hip_status amg_hip_apply(amg_hip_solver* s, const double* v_dev, double* z_dev);
+/* Preconditioned conjugate gradients for A_0 x = b with M^-1 = amg_hip_apply, entirely on the
+ * device (SpMV, dot products, updates; alpha / beta never leave it).  Starts from the current
+ * level-0 solution, replaces it with the result.  Stops when ||b - A x||_2 <= rtol ||b||_2
+ * (checked every iteration) or after max_iters.  The smoother must make the cycle a
+ * symmetric operator: SparseGaussSeidel (forward + backward), true Jacobi or multicolour GS
+ * with equal pre / post sweeps all do.  A is the reference's negative definite Laplacian
+ * (grid.hpp:88-98): CG runs on it unchanged (r.z and p.Ap are both negative).            */
+amg_hip_status amg_hip_pcg(amg_hip_solver* s, double rtol, int64_t max_iters, int64_t* iters,
+                           double* relres);
+
 /* AMG::rss(A_0, u_0, b), common.hpp:17-27 (device tree reduction; agrees with
  * the sequential sum to ~1e-15 relative). */
 amg_hip_status amg_hip_rss(amg_hip_solver* s, double* out);

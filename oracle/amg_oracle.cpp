@@ -806,6 +806,63 @@ uint64_t orc_mg_solve(void* h, double tol, uint64_t every, uint64_t n_iters,
   return mg_solve((Multigrid*)h, tol, every, n_iters, converged, last_rss,
                   trajectory, traj_cap);
 }
+// The V-cycle as a preconditioner (README.md:127 of the reference, its ref [7]): z = M^-1 v
+// is one mg_vcycle() from the zero vector with v as the level-0 right-hand side.  The
+// reference only names this use; the twin below is what the product's amg_hip_apply /
+// amg_hip_pcg are compared with ("parity unpinned" against the reference itself).
+void orc_mg_apply(void* h, const double* v, double* z) {
+  Multigrid* M = (Multigrid*)h;
+  const std::vector<double> f_save = M->f[0], u_save = M->u[0];
+  M->f[0].assign(v, v + f_save.size());
+  std::fill(M->u[0].begin(), M->u[0].end(), 0.0);
+  mg_vcycle(M);
+  std::memcpy(z, M->u[0].data(), sizeof(double) * f_save.size());
+  M->f[0] = f_save;
+  M->u[0] = u_save;
+}
+// Textbook PCG on A_0 x = b (x starts at the level-0 solution and replaces it); stops when
+// ||r|| <= rtol ||b|| or after max_iters.  Sequential dot products, separate multiply / add.
+uint64_t orc_mg_pcg(void* h, double rtol, uint64_t max_iters, double* relres) {
+  Multigrid* M = (Multigrid*)h;
+  const Csc& A = M->A[0];
+  const size_t n = (size_t)A.rows;
+  const std::vector<double> b = M->f[0];
+  std::vector<double> x = M->u[0], r(n), z(n), p(n), q(n);
+  auto dot = [&](const std::vector<double>& a, const std::vector<double>& c) {
+    double s = 0.0;
+    for (size_t i = 0; i < n; ++i) s += a[i] * c[i];
+    return s;
+  };
+  const double bnorm = std::sqrt(dot(b, b));
+  residual(A, x.data(), b.data(), r.data());
+  uint64_t it = 0;
+  double rel = bnorm > 0 ? std::sqrt(dot(r, r)) / bnorm : std::sqrt(dot(r, r));
+  if (rel > rtol && max_iters > 0) {
+    orc_mg_apply(h, r.data(), z.data());
+    p = z;
+    double rz = dot(r, z);
+    while (it < max_iters) {
+      spmv(A, p.data(), q.data());
+      const double alpha = rz / dot(p, q);
+      for (size_t i = 0; i < n; ++i) {
+        x[i] = x[i] + alpha * p[i];
+        r[i] = r[i] - alpha * q[i];
+      }
+      it += 1;
+      const double rr = dot(r, r);
+      rel = bnorm > 0 ? std::sqrt(rr) / bnorm : std::sqrt(rr);
+      if (!(rel > rtol) || it >= max_iters) break;
+      orc_mg_apply(h, r.data(), z.data());
+      const double rzn = dot(r, z);
+      const double beta = rzn / rz;
+      for (size_t i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
+      rz = rzn;
+    }
+  }
+  M->u[0] = x;
+  if (relres) *relres = rel;
+  return it;
+}
 // CPU baseline: wall seconds for n consecutive vcycle() calls (single thread;
 // the reference has no threading).  rss is not called.
 double orc_mg_time_vcycles(void* h, uint64_t n) {

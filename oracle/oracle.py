@@ -98,6 +98,10 @@ def _bind(L):
     L.orc_mg_solve.restype = C.c_uint64
     L.orc_mg_solve.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint64,
                                C.POINTER(C.c_int), _f64p, _f64p, C.c_uint64]
+    L.orc_mg_apply.restype = None
+    L.orc_mg_apply.argtypes = [C.c_void_p, _f64p, _f64p]
+    L.orc_mg_pcg.restype = C.c_uint64
+    L.orc_mg_pcg.argtypes = [C.c_void_p, C.c_double, C.c_uint64, _f64p]
     L.orc_mg_time_vcycles.restype = C.c_double
     L.orc_mg_time_vcycles.argtypes = [C.c_void_p, C.c_uint64]
     return L
@@ -325,6 +329,19 @@ class Multigrid:
                                 C.byref(last), _p64(traj), cap)
         k = int(it) // every
         return int(it), bool(conv.value), last.value, traj[:k].copy()
+
+    def apply(self, v):
+        """z = M^-1 v: one V-cycle from zero with v as the right-hand side."""
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        z = np.empty_like(v)
+        self._L.orc_mg_apply(self._h, _p64(v), _p64(z))
+        return z
+
+    def pcg(self, rtol=1e-10, max_iters=100):
+        """CG preconditioned with one V-cycle; returns (x, iters, relres)."""
+        rel = C.c_double(0)
+        it = self._L.orc_mg_pcg(self._h, rtol, max_iters, C.byref(rel))
+        return self.get_vec(0, "u"), int(it), rel.value
 
     def time_vcycles(self, n):
         return self._L.orc_mg_time_vcycles(self._h, n)

@@ -10,6 +10,7 @@
 #include <amg/grid.hpp>
 #include <amg/interpolator.hpp>
 #include <amg/multigrid.hpp>
+#include <amg/pcg.hpp>
 #include <amg/smoother.hpp>
 
 static int n_checks = 0, n_failed = 0;
@@ -166,6 +167,23 @@ int main() {
     bool same = ua.size() == ub.size();
     for (Eigen::Index i = 0; same && i < ua.size(); ++i) same = (ua[i] == ub[i]);
     CHECK(same);
+  }
+
+  // the V-cycle as a preconditioner (reference README.md:127): AMG::PCG on the same problem
+  {
+    AMG::LinearInterpolator<double> interp5(8);
+    AMG::SparseGaussSeidel<double> pre;
+    AMG::Multigrid<double> amg_pc(&interp5, &pre, amg_A, amg_b, n_levels, 1e-9, 5, 100);
+    AMG::PCG<double> pcg(&amg_pc, 1e-10, 50);
+    auto x = pcg.solve();
+    CHECK(pcg.relative_residual() <= 1e-10);
+    CHECK(pcg.iterations() < 35);                       // plain V-cycles needed 35
+    CHECK(x.isApprox(amg_u, 1e-6));
+    UserJacobi uj2(0.6);
+    AMG::LinearInterpolator<double> interp6(8);
+    AMG::Multigrid<double> amg_host(&interp6, &uj2, amg_A, amg_b, 4, 1e-9, 5, 50);
+    auto bad_pcg = [&]() { AMG::PCG<double> p2(&amg_host); };
+    CHECK_THROWS_AS(bad_pcg(), std::invalid_argument);
   }
 
   std::cout << (n_failed ? "SOME TESTS FAILED" : "All tests passed") << " (" << n_checks
