@@ -82,6 +82,8 @@ _SIGS = {
                                         C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_f64p),
                                         C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_f64p),
                                         C.POINTER(Options), C.POINTER(C.c_void_p)]),
+    "amg_hip_create_poisson": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.POINTER(Options),
+                                         C.POINTER(C.c_void_p)]),
     "amg_hip_destroy": (None, [C.c_void_p]),
     "amg_hip_vcycle": (C.c_int, [C.c_void_p]),
     "amg_hip_vcycles": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -294,23 +296,9 @@ class Multigrid:
         self.tolerance = tolerance
         self.every = compute_error_every_n_iters
         self.n_iters = n_iters
-        o = Options()
-        lib().amg_hip_default_options(C.byref(o))
-        o.smoother, o.smoother_iters, o.omega = smoother, smoother_iters, omega
-        o.device, o.use_graph, o.stencil_transfers = device, int(use_graph), int(stencil_transfers)
-        if layout is not None:
-            o.layout = layout
-        o.host_only = int(host_only)
-        o.keep_structural_zeros = int(keep_structural_zeros)
-        o.no_fusion = int(no_fusion)
-        o.fuse_prolong = int(fuse_prolong)
-        o.fast_coarse_solve = int(fast_coarse_solve)
-        o.host_galerkin = int(host_galerkin)
-        o.keep_residual = int(keep_residual)
-        o.exact_coarse_solve = int(exact_coarse_solve)
-        o.exact_gs = int(exact_gs)
-        if stream:
-            o.stream = C.c_void_p(stream)
+        o = self._options(smoother, smoother_iters, omega, device, use_graph, stencil_transfers, layout,
+                          host_only, keep_structural_zeros, no_fusion, fuse_prolong, stream,
+                          fast_coarse_solve, host_galerkin, keep_residual, exact_coarse_solve, exact_gs)
         h = C.c_void_p()
         if transfers is None:
             st = lib().amg_hip_create(n, _p32(colptr), _p32(rowind), _p64(val), _p64(b),
@@ -340,6 +328,53 @@ class Multigrid:
             raise ValueError(lib().amg_hip_last_error().decode())
         _chk(st)
         self._h = h
+
+    @staticmethod
+    def _options(smoother, smoother_iters, omega, device, use_graph, stencil_transfers, layout,
+                 host_only, keep_structural_zeros, no_fusion, fuse_prolong, stream,
+                 fast_coarse_solve, host_galerkin, keep_residual, exact_coarse_solve, exact_gs):
+        o = Options()
+        lib().amg_hip_default_options(C.byref(o))
+        o.smoother, o.smoother_iters, o.omega = smoother, smoother_iters, omega
+        o.device, o.use_graph, o.stencil_transfers = device, int(use_graph), int(stencil_transfers)
+        if layout is not None:
+            o.layout = layout
+        o.host_only = int(host_only)
+        o.keep_structural_zeros = int(keep_structural_zeros)
+        o.no_fusion = int(no_fusion)
+        o.fuse_prolong = int(fuse_prolong)
+        o.fast_coarse_solve = int(fast_coarse_solve)
+        o.host_galerkin = int(host_galerkin)
+        o.keep_residual = int(keep_residual)
+        o.exact_coarse_solve = int(exact_coarse_solve)
+        o.exact_gs = int(exact_gs)
+        if stream:
+            o.stream = C.c_void_p(stream)
+        return o
+
+    @classmethod
+    def poisson(cls, n, n_levels, dim=2, smoother=SM_SPGS, smoother_iters=1, omega=1.0, tolerance=1e-9,
+                compute_error_every_n_iters=10, n_iters=100, device=-1, use_graph=True,
+                stencil_transfers=True, layout=None, keep_structural_zeros=False, no_fusion=False,
+                stream=None, fast_coarse_solve=False, keep_residual=False, exact_coarse_solve=False,
+                exact_gs=False):
+        """AMG::Multigrid on A = Grid::laplacian(n), b = Grid::rhs(n) with the setup on the device
+        end to end (amg_hip_create_poisson): no host matrices."""
+        if compute_error_every_n_iters > n_iters:
+            raise ValueError("`compute_error_every_n_iters` must be leq to `n_iters`, got "
+                             f"{compute_error_every_n_iters} and {n_iters}")
+        self = cls.__new__(cls)
+        self.tolerance, self.every, self.n_iters = tolerance, compute_error_every_n_iters, n_iters
+        o = cls._options(smoother, smoother_iters, omega, device, use_graph, stencil_transfers, layout,
+                         False, keep_structural_zeros, no_fusion, False, stream, fast_coarse_solve,
+                         False, keep_residual, exact_coarse_solve, exact_gs)
+        h = C.c_void_p()
+        st = lib().amg_hip_create_poisson(dim, n, n_levels, C.byref(o), C.byref(h))
+        if st == EINVAL:
+            raise ValueError(lib().amg_hip_last_error().decode())
+        _chk(st)
+        self._h = h
+        return self
 
     def close(self):
         if getattr(self, "_h", None):

@@ -847,24 +847,28 @@ Sparse laplacian(int dim, int64_t n) {
   return A;
 }
 
-void rhs(int dim, int64_t n, double* b) {
+void rhs_range(int dim, int64_t n, double* b, int64_t d0, int64_t d1) {
   // grid.hpp:108-140 with Eigen's LinSpaced(n+2, -1, 1):
   // x_i = (i == n+1) ? 1 : -1 + i*step, step = 2/(n+1).
   const int64_t np = n + 2;
   const double step = (1.0 - (-1.0)) / (double)(np - 1);
   std::vector<double> x(np);
   for (int64_t i = 0; i < np; ++i) x[i] = (i == np - 1) ? 1.0 : -1.0 + (double)i * step;
-  int64_t dof = 0;
-  if (dim == 2) {
-    for (int64_t j = 1; j <= n; ++j)
-      for (int64_t i = 1; i <= n; ++i)
-        b[dof++] = 5 * std::exp(-10 * (x[j] * x[j] + x[i] * x[i]));
-  } else {
-    for (int64_t k = 1; k <= n; ++k)
-      for (int64_t j = 1; j <= n; ++j)
-        for (int64_t i = 1; i <= n; ++i)
-          b[dof++] = 5 * std::exp(-10 * ((x[k] * x[k] + x[j] * x[j]) + x[i] * x[i]));
+  for (int64_t dof = d0; dof < d1; ++dof) {
+    const int64_t i = dof % n + 1, j = (dof / n) % n + 1;
+    if (dim == 2) {
+      b[dof] = 5 * std::exp(-10 * (x[j] * x[j] + x[i] * x[i]));
+    } else {
+      const int64_t k = dof / (n * n) + 1;
+      b[dof] = 5 * std::exp(-10 * ((x[k] * x[k] + x[j] * x[j]) + x[i] * x[i]));
+    }
   }
+}
+
+void rhs(int dim, int64_t n, double* b) {
+  int64_t N = n * n;
+  if (dim == 3) N *= n;
+  rhs_range(dim, n, b, 0, N);
 }
 
 }  // namespace amg_hip

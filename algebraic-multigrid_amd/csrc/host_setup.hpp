@@ -189,5 +189,6 @@ void build_color_perm(const Sparse& rows_as, const std::vector<int32_t>& color,
 // ---- Grid<double> (grid.hpp) ------------------------------------------------
 Sparse laplacian(int dim, int64_t n);       // CSC (== CSR, symmetric)
 void rhs(int dim, int64_t n, double* b);
+void rhs_range(int dim, int64_t n, double* b, int64_t dof0, int64_t dof1);  // entries [dof0, dof1)
 
 }  // namespace amg_hip

@@ -2778,4 +2778,172 @@ hipError_t launch_galerkin_rap(bool fill, int64_t n_h, int64_t n_H, const int32_
   return hipGetLastError();
 }
 
+// --------------------------------------------------------------- K-Setup ------
+// Setup on the device end to end: the Grid generators
+// (grid.hpp:88-98 and the 7-point analogue) as kernels, and the dictionary encoder of the
+// level matrices, so that a Poisson hierarchy never exists as host arrays unless a getter
+// asks for one.
+// A = sum over axes of I (x) .. D .. (x) I, D = tridiag(1, -2, 1) / h^2: row c holds its lower
+// neighbours (axes dim-1 .. 0), the diagonal, its upper neighbours (axes 0 .. dim-1) --
+// ascending columns, the order host_setup.cpp: laplacian() produces.
+__global__ __launch_bounds__(256) void lap_count_kernel(int dim, int64_t n, int64_t N,
+                                                        int32_t* __restrict__ cnt) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  const int64_t co[3] = {c % n, (c / n) % n, c / (n * n)};
+  int k = 1;
+  for (int a = 0; a < dim; ++a) k += (co[a] > 0) + (co[a] + 1 < n);
+  cnt[c] = k;
+}
+__global__ __launch_bounds__(256) void lap_fill_kernel(int dim, int64_t n, int64_t N,
+                                                       const int32_t* __restrict__ rowptr,
+                                                       int32_t* __restrict__ col,
+                                                       double* __restrict__ val, double off,
+                                                       double diag) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  const int64_t co[3] = {c % n, (c / n) % n, c / (n * n)};
+  const int64_t st[3] = {1, n, n * n};
+  int64_t p = rowptr[c];
+  for (int a = dim - 1; a >= 0; --a)
+    if (co[a] > 0) { col[p] = (int32_t)(c - st[a]); val[p] = off; ++p; }
+  col[p] = (int32_t)c; val[p] = diag; ++p;
+  for (int a = 0; a < dim; ++a)
+    if (co[a] + 1 < n) { col[p] = (int32_t)(c + st[a]); val[p] = off; ++p; }
+}
+hipError_t launch_laplacian_count(int dim, int64_t n, int64_t N, int32_t* cnt, hipStream_t st) {
+  hipLaunchKernelGGL(lap_count_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dim, n, N, cnt);
+  return hipGetLastError();
+}
+hipError_t launch_laplacian_fill(int dim, int64_t n, int64_t N, const int32_t* rowptr, int32_t* col,
+                                 double* val, double off, double diag, hipStream_t st) {
+  hipLaunchKernelGGL(lap_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dim, n, N,
+                     rowptr, col, val, off, diag);
+  return hipGetLastError();
+}
+
+// stats[0] = longest row (entries that are kept), stats[1] = 1 when the matrix is not
+// bitwise symmetric, diag[i] = a_ii (0.0 when absent).  prune: exact zeros do not count.
+__global__ __launch_bounds__(256) void csr_inspect_kernel(int64_t n, const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ col,
+                                                          const double* __restrict__ val, int prune,
+                                                          int32_t* __restrict__ stats,
+                                                          double* __restrict__ diag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int len = 0;
+  double d = 0.0;
+  bool asym = false;
+  for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+    const int32_t j = col[p];
+    const double v = val[p];
+    if (!prune || v != 0.0) ++len;
+    if (j == i) { d = v; continue; }
+    // (j, i) must hold the same bits: binary search in row j
+    int32_t lo = rowptr[j], hi = rowptr[j + 1] - 1;
+    bool found = false;
+    while (lo <= hi) {
+      const int32_t mid = (lo + hi) >> 1;
+      const int32_t cm = col[mid];
+      if (cm == (int32_t)i) {
+        found = __double_as_longlong(val[mid]) == __double_as_longlong(v);
+        break;
+      }
+      if (cm < (int32_t)i) lo = mid + 1;
+      else hi = mid - 1;
+    }
+    asym = asym || !found;
+  }
+  if (diag) diag[i] = d;
+  atomicMax(&stats[0], len);
+  if (asym) atomicOr(&stats[1], 1);
+}
+hipError_t launch_csr_inspect(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val,
+                              bool prune, int32_t* stats, double* diag, hipStream_t st) {
+  hipLaunchKernelGGL(csr_inspect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, rowptr,
+                     col, val, prune ? 1 : 0, stats, diag);
+  return hipGetLastError();
+}
+
+// Dictionary encoder: row r -> `words` 64-bit words of byte codes into the pair table
+// (doff, dval: <= 255 entries in LDS), entries in ascending column order, exact zeros skipped
+// when prune.  A pair that is not in the table makes the row a FAILURE: its index goes to
+// fail[1 + slot] (first 62 of them, fail[0] counts all) and the host, which proposed the
+// table from a sample of rows, adds the row's pairs and runs the pass again -- the encoding is
+// exact because every row is checked, however the table was guessed.
+__global__ __launch_bounds__(256) void dict_encode_kernel(
+    int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const double* __restrict__ val, int prune, const int32_t* __restrict__ doff,
+    const double* __restrict__ dval, int ntab, int words, uint64_t* __restrict__ codes,
+    int32_t* __restrict__ fail) {
+  __shared__ int32_t toff[256];
+  __shared__ long long tval[256];
+  if ((int)threadIdx.x < ntab) {
+    toff[threadIdx.x] = doff[threadIdx.x];
+    tval[threadIdx.x] = __double_as_longlong(dval[threadIdx.x]);
+  }
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  uint64_t w[2] = {~(uint64_t)0, ~(uint64_t)0};
+  int k = 0;
+  bool bad = false;
+  for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+    const double v = val[p];
+    if (prune && v == 0.0) continue;
+    const int32_t o = (int32_t)((int64_t)col[p] - r);
+    const long long vb = __double_as_longlong(v);
+    int code = -1;
+    for (int t = 0; t < ntab; ++t)
+      if (toff[t] == o && tval[t] == vb) { code = t; break; }
+    if (code < 0 || k >= 8 * words) { bad = true; break; }
+    w[k >> 3] = (w[k >> 3] & ~((uint64_t)0xFF << (8 * (k & 7)))) | ((uint64_t)code << (8 * (k & 7)));
+    ++k;
+  }
+  if (bad) {
+    const int32_t slot = atomicAdd(&fail[0], 1);
+    if (slot < 62) fail[1 + slot] = (int32_t)r;
+    return;
+  }
+  for (int q = 0; q < words; ++q) codes[r * words + q] = w[q];
+}
+// second level: code words -> one byte per row into the word table (<= 255 types; a row
+// without entries is type 255); unknown words are failures as above
+__global__ __launch_bounds__(256) void dict_type_kernel(int64_t n, const uint64_t* __restrict__ codes,
+                                                        int words, const uint64_t* __restrict__ rwords,
+                                                        int ntypes, uint8_t* __restrict__ rtype,
+                                                        int32_t* __restrict__ fail) {
+  __shared__ uint64_t tw[512];
+  for (int t = threadIdx.x; t < ntypes * words; t += 256) tw[t] = rwords[t];
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t a = codes[r * words], b = words == 2 ? codes[r * 2 + 1] : ~(uint64_t)0;
+  if (a == ~(uint64_t)0 && b == ~(uint64_t)0) { rtype[r] = 255; return; }
+  int ty = -1;
+  for (int t = 0; t < ntypes; ++t)
+    if (tw[t * words] == a && (words == 1 || tw[t * 2 + 1] == b)) { ty = t; break; }
+  if (ty < 0) {
+    const int32_t slot = atomicAdd(&fail[0], 1);
+    if (slot < 62) fail[1 + slot] = (int32_t)r;
+    return;
+  }
+  rtype[r] = (uint8_t)ty;
+}
+hipError_t launch_dict_encode(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val,
+                              bool prune, const int32_t* doff, const double* dval, int ntab, int words,
+                              uint64_t* codes, int32_t* fail, hipStream_t st) {
+  if (ntab > 255 || (words != 1 && words != 2)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dict_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, rowptr,
+                     col, val, prune ? 1 : 0, doff, dval, ntab, words, codes, fail);
+  return hipGetLastError();
+}
+hipError_t launch_dict_types(int64_t n, const uint64_t* codes, int words, const uint64_t* rwords,
+                             int ntypes, uint8_t* rtype, int32_t* fail, hipStream_t st) {
+  if (ntypes > 255 || (words != 1 && words != 2)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dict_type_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, codes,
+                     words, rwords, ntypes, rtype, fail);
+  return hipGetLastError();
+}
+
 }  // namespace amg_hip

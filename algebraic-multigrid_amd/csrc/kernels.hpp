@@ -229,4 +229,19 @@ hipError_t launch_galerkin_rap(bool fill, int64_t n_h, int64_t n_H, const int32_
                                const int32_t* pcol, const double* pval, int32_t* cnt,
                                const int32_t* orp, int32_t* ocol, double* oval, hipStream_t st);
 
+// K-Setup: Grid generators and the dictionary encoder on the device (kernels.hip)
+hipError_t launch_laplacian_count(int dim, int64_t n, int64_t N, int32_t* cnt, hipStream_t st);
+hipError_t launch_laplacian_fill(int dim, int64_t n, int64_t N, const int32_t* rowptr, int32_t* col,
+                                 double* val, double off, double diag, hipStream_t st);
+// stats[0] = longest row (exact zeros skipped when prune), stats[1] = 1 when not bitwise
+// symmetric (both zero-initialised by the caller); diag (optional) = a_ii
+hipError_t launch_csr_inspect(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val,
+                              bool prune, int32_t* stats, double* diag, hipStream_t st);
+// fail: 64 int32, zero-initialised: [0] = rows that did not encode, [1..62] = their indices
+hipError_t launch_dict_encode(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val,
+                              bool prune, const int32_t* doff, const double* dval, int ntab, int words,
+                              uint64_t* codes, int32_t* fail, hipStream_t st);
+hipError_t launch_dict_types(int64_t n, const uint64_t* codes, int words, const uint64_t* rwords,
+                             int ntypes, uint8_t* rtype, int32_t* fail, hipStream_t st);
+
 }  // namespace amg_hip

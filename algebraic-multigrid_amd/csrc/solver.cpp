@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <thread>
@@ -161,6 +162,7 @@ hipError_t device_galerkin(const DevCsr& A, int64_t n_H, DevCsr* AH, Sparse* hos
     return e;
   AH->n_rows = AH->n_cols = n_H;
   AH->nnz = nnz;
+  if (!host) return hipSuccess;  // device-only setup: the host copy is made when a getter asks
   host->n_outer = host->n_inner = n_H;
   host->ptr.resize(n_H + 1);
   host->idx.resize(nnz);
@@ -256,7 +258,7 @@ hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift
 // {off-diagonal value, diagonal value, value, LDS offset} per (type, slot).
 bool build_patch_table(const DictMat& T, int64_t n, int64_t* m_out, int* un_out, int* ntypes_out,
                        std::vector<double>* tab) {
-  if (T.rtype.empty() || T.max_width > 9 || T.doff.empty()) return false;
+  if (T.rwords.empty() || T.max_width > 9 || T.doff.empty()) return false;
   int64_t omax = 0;
   for (int32_t o : T.doff) omax = std::max<int64_t>(omax, o < 0 ? -(int64_t)o : o);
   int ntypes = 0;
@@ -300,6 +302,74 @@ bool build_patch_table(const DictMat& T, int64_t n, int64_t* m_out, int* un_out,
   return false;
 }
 
+// Common tail of the dictionary upload (host encoder: upload_mat; device encoder:
+// device_dict_encode): the tables, the layout flags, the K-GS-scan distances and the K-Patch
+// tables.  D->dict_typed and the per-row arrays (drtype or dcodes) are set by the caller;
+// T needs words, max_width, doff, dval and, when typed, rwords.
+hipError_t finish_dict(const DictMat& T, int64_t n, int64_t diag_shift, DevMat* D) {
+  hipError_t e;
+  D->dict = true;
+  D->sell = false;
+  D->dict_words = T.words;
+  D->dict_wmax = T.max_width;
+  D->dict_ntab = (int)T.doff.size();
+  D->dict_shift = diag_shift;
+  D->dict_hb = 0;
+  for (int32_t o : T.doff) D->dict_hb = std::max<int>(D->dict_hb, o < 0 ? -o : o);
+  // one sweep streams codes + f + out and gathers x: non-temporal stream when
+  // that is well beyond the 256 MiB Infinity Cache
+  const double stream_bytes = (double)n * ((D->dict_typed ? 1.0 : 8.0 * T.words) + 24.0);
+  D->dict_nt = (g_nontemporal && stream_bytes > 192.0e6) ? 1 : 0;
+  if (D->dict_typed)
+    if ((e = upload(D->drwords, T.rwords.data(), T.rwords.size())) != hipSuccess) return e;
+  if ((e = upload(D->doff, T.doff.data(), T.doff.size())) != hipSuccess) return e;
+  if ((e = upload(D->dval, T.dval.data(), T.dval.size())) != hipSuccess) return e;
+  D->scan_gap = D->scan_far = 0;
+  if (diag_shift == 0) {
+    int64_t gap = INT64_MAX, far = 1;
+    for (int32_t o : T.doff) {
+      const int64_t a = o < 0 ? -(int64_t)o : o;
+      if (a >= 2) gap = std::min(gap, a);
+      far = std::max(far, a);
+    }
+    D->scan_gap = gap == INT64_MAX ? (int64_t)1 << 20 : gap;
+    D->scan_far = far;
+  }
+  D->patch = false;
+  if (D->dict_typed && diag_shift == 0) {
+    std::vector<double> tab;
+    if (build_patch_table(T, n, &D->patch_m, &D->patch_un, &D->patch_ntypes, &tab)) {
+      if ((e = upload(D->patch_tab, tab.data(), tab.size())) != hipSuccess) return e;
+      // per-type form for the wave-uniform path (+ the all-absent type `ntypes`)
+      const int un = D->patch_un, nty = D->patch_ntypes;
+      std::vector<double> ud((size_t)(nty + 1) * (2 * un + 1), 0.0);
+      std::vector<int32_t> ui((size_t)(nty + 1) * (un + 2), 0);
+      for (int t = 0; t < nty; ++t) {
+        double diag = 0.0;
+        uint32_t jm = 0, rm = 0;
+        for (int k = 0; k < un; ++k) {
+          const double* q = &tab[((size_t)t * un + k) * 4];
+          const bool used = q[3] > -1.0e8;
+          ud[(size_t)t * (2 * un + 1) + k] = q[0];
+          ud[(size_t)t * (2 * un + 1) + un + k] = q[2];
+          diag += q[1];  // dict_rows' order: +0.0 except the diagonal slot
+          ui[(size_t)t * (un + 2) + k] = used ? (int32_t)q[3] : 0;
+          // slots whose Jacobi value is +0.0 (unused, diagonal, pruned) add nothing
+          if (used && q[0] != 0.0) jm |= 1u << k;
+          if (used) rm |= 1u << k;
+        }
+        ud[(size_t)t * (2 * un + 1) + 2 * un] = diag;
+        ui[(size_t)t * (un + 2) + un] = (int32_t)jm;
+        ui[(size_t)t * (un + 2) + un + 1] = (int32_t)rm;
+      }
+      if ((e = upload(D->patch_utabd, ud.data(), ud.size())) != hipSuccess) return e;
+      if ((e = upload(D->patch_utabi, ui.data(), ui.size())) != hipSuccess) return e;
+      D->patch = true;
+    }
+  }
+  return hipSuccess;
+}
+
 hipError_t upload_mat_pruned(const Sparse& M, int layout, bool prune, DevMat* D,
                              int64_t diag_shift = 0) {
   bool any = false;
@@ -327,72 +397,13 @@ hipError_t upload_mat(const Sparse& M, int layout, DevMat* D, int64_t diag_shift
     DictMat T;
     if (to_dict(M, diag_shift, &T)) {
       hipError_t e;
-      D->dict = true;
-      D->sell = false;
-      D->dict_words = T.words;
-      D->dict_wmax = T.max_width;
-      D->dict_ntab = (int)T.doff.size();
-      D->dict_shift = diag_shift;
-      D->dict_hb = 0;
-      for (int32_t o : T.doff) D->dict_hb = std::max<int>(D->dict_hb, o < 0 ? -o : o);
-      // one sweep streams codes + f + out and gathers x: non-temporal stream when
-      // that is well beyond the 256 MiB Infinity Cache
       D->dict_typed = g_row_types != 0 && !T.rtype.empty();
-      const double stream_bytes =
-          (double)M.n_outer * ((D->dict_typed ? 1.0 : 8.0 * T.words) + 24.0);
-      D->dict_nt = (g_nontemporal && stream_bytes > 192.0e6) ? 1 : 0;
       if (D->dict_typed) {  // the kernels then never touch the per-row code words
         if ((e = upload(D->drtype, T.rtype.data(), T.rtype.size())) != hipSuccess) return e;
-        if ((e = upload(D->drwords, T.rwords.data(), T.rwords.size())) != hipSuccess) return e;
       } else {
         if ((e = upload(D->dcodes, T.codes.data(), T.codes.size())) != hipSuccess) return e;
       }
-      if ((e = upload(D->doff, T.doff.data(), T.doff.size())) != hipSuccess) return e;
-      if ((e = upload(D->dval, T.dval.data(), T.dval.size())) != hipSuccess) return e;
-      D->scan_gap = D->scan_far = 0;
-      if (diag_shift == 0) {
-        int64_t gap = INT64_MAX, far = 1;
-        for (int32_t o : T.doff) {
-          const int64_t a = o < 0 ? -(int64_t)o : o;
-          if (a >= 2) gap = std::min(gap, a);
-          far = std::max(far, a);
-        }
-        D->scan_gap = gap == INT64_MAX ? (int64_t)1 << 20 : gap;
-        D->scan_far = far;
-      }
-      D->patch = false;
-      if (D->dict_typed && diag_shift == 0) {
-        std::vector<double> tab;
-        if (build_patch_table(T, M.n_outer, &D->patch_m, &D->patch_un, &D->patch_ntypes, &tab)) {
-          if ((e = upload(D->patch_tab, tab.data(), tab.size())) != hipSuccess) return e;
-          // per-type form for the wave-uniform path (+ the all-absent type `ntypes`)
-          const int un = D->patch_un, nty = D->patch_ntypes;
-          std::vector<double> ud((size_t)(nty + 1) * (2 * un + 1), 0.0);
-          std::vector<int32_t> ui((size_t)(nty + 1) * (un + 2), 0);
-          for (int t = 0; t < nty; ++t) {
-            double diag = 0.0;
-            uint32_t jm = 0, rm = 0;
-            for (int k = 0; k < un; ++k) {
-              const double* q = &tab[((size_t)t * un + k) * 4];
-              const bool used = q[3] > -1.0e8;
-              ud[(size_t)t * (2 * un + 1) + k] = q[0];
-              ud[(size_t)t * (2 * un + 1) + un + k] = q[2];
-              diag += q[1];  // dict_rows' order: +0.0 except the diagonal slot
-              ui[(size_t)t * (un + 2) + k] = used ? (int32_t)q[3] : 0;
-              // slots whose Jacobi value is +0.0 (unused, diagonal, pruned) add nothing
-              if (used && q[0] != 0.0) jm |= 1u << k;
-              if (used) rm |= 1u << k;
-            }
-            ud[(size_t)t * (2 * un + 1) + 2 * un] = diag;
-            ui[(size_t)t * (un + 2) + un] = (int32_t)jm;
-            ui[(size_t)t * (un + 2) + un + 1] = (int32_t)rm;
-          }
-          if ((e = upload(D->patch_utabd, ud.data(), ud.size())) != hipSuccess) return e;
-          if ((e = upload(D->patch_utabi, ui.data(), ui.size())) != hipSuccess) return e;
-          D->patch = true;
-        }
-      }
-      return hipSuccess;
+      return finish_dict(T, M.n_outer, diag_shift, D);
     }
     if (layout == AMG_HIP_LAYOUT_DICT) layout = AMG_HIP_LAYOUT_SELL;
   }
@@ -584,7 +595,25 @@ hipError_t upload_lex(const LexSchedule& S, LexOnDev* L) {
 
 struct Level {
   int64_t n = 0;
-  Sparse A_csc;            // host copy, what get_coefficient_matrix returns
+  int64_t nnz_struct = 0;  // structural entries (exact zeros of the Galerkin product included)
+  // host copy, what get_coefficient_matrix returns.  Device-only setup (amg_hip_create_poisson)
+  // leaves it empty and keeps CSR(A) on the device instead; host_matrix() fills it on demand.
+  mutable Sparse A_csc;
+  DevCsr A_dev;
+  const Sparse& host_matrix() const {
+    if (A_csc.ptr.empty() && A_dev.n_rows > 0) {  // symmetric: the CSR arrays are the CSC arrays
+      A_csc.n_outer = A_csc.n_inner = A_dev.n_rows;
+      A_csc.ptr.resize((size_t)A_dev.n_rows + 1);
+      A_csc.idx.resize((size_t)A_dev.nnz);
+      A_csc.val.resize((size_t)A_dev.nnz);
+      (void)hipMemcpy(A_csc.ptr.data(), A_dev.ptr.p, sizeof(int32_t) * A_csc.ptr.size(), hipMemcpyDeviceToHost);
+      if (A_dev.nnz > 0) {
+        (void)hipMemcpy(A_csc.idx.data(), A_dev.idx.p, sizeof(int32_t) * A_csc.idx.size(), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(A_csc.val.data(), A_dev.val.p, sizeof(double) * A_csc.val.size(), hipMemcpyDeviceToHost);
+      }
+    }
+    return A_csc;
+  }
   DevMat A_rows;           // rows of A: residual, rss
   DevMat A_cols_own;       // CSC arrays walked as rows (column-as-row smoothers,
   bool symmetric = false;  //   smoother.hpp:101-117); aliases A_rows when bitwise equal
@@ -989,7 +1018,7 @@ void compute_bytes(amg_hip_solver* s) {
     sweeps_per_smooth = 2 * iters;
   for (int l = 0; l < nl; ++l) {
     const Level& L = s->lv[l];
-    const double sweep = 12.0 * (double)L.A_csc.nnz() + 28.0 * (double)L.n;
+    const double sweep = 12.0 * (double)L.nnz_struct + 28.0 * (double)L.n;
     if (l == 0) s->fine_sweep_bytes = sweep;
     // pre-smooth + residual on every level; post-smooth on all but the coarsest
     total += sweep * (sweeps_per_smooth + 1);
@@ -1087,6 +1116,7 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
   for (int l = 0; l < n_levels; ++l) {
     Level& L = s->lv[l];
     L.symmetric = same_arrays(A_r, L.A_csc);
+    L.nnz_struct = L.A_csc.nnz();
     if (dev) {
     const bool prune = !s->opt.keep_structural_zeros;
     HIP_TRY(upload_mat_pruned(A_r, s->opt.layout, prune, &L.A_rows));
@@ -1244,11 +1274,314 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
   return AMG_HIP_OK;
 }
 
+// ---- setup on the device end to end (amg_hip_create_poisson) -------------------
+// Dictionary encoding of CSR(A) that sits on the device (K-Setup: dict_encode_kernel,
+// dict_type_kernel).  The pair table and the word table are PROPOSED by the host from a
+// sample of rows (first and last 64 K) and VERIFIED by the kernels on every row; rows that
+// do not encode are reported back, their pairs / words are added, and the pass is repeated.
+// Returns false (D untouched in the sense of dict = false) when the matrix does not qualify.
+struct HostRows {  // rows [r0, r1) of a device CSR matrix
+  int64_t r0 = 0;
+  std::vector<int32_t> ptr, col;
+  std::vector<double> val;
+};
+hipError_t fetch_rows(const DevCsr& A, int64_t r0, int64_t r1, HostRows* R) {
+  R->r0 = r0;
+  R->ptr.resize((size_t)(r1 - r0 + 1));
+  hipError_t e = hipMemcpy(R->ptr.data(), A.rowptr() + r0, sizeof(int32_t) * R->ptr.size(), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return e;
+  const int64_t p0 = R->ptr.front(), p1 = R->ptr.back();
+  R->col.resize((size_t)(p1 - p0));
+  R->val.resize((size_t)(p1 - p0));
+  if (p1 > p0) {
+    if ((e = hipMemcpy(R->col.data(), A.col() + p0, sizeof(int32_t) * (p1 - p0), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+    if ((e = hipMemcpy(R->val.data(), A.v() + p0, sizeof(double) * (p1 - p0), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+hipError_t device_dict_encode(const DevCsr& A, bool prune, int maxlen, DevMat* D, bool* ok) {
+  *ok = false;
+  const int64_t n = A.n_rows;
+  if (maxlen > 16 || n >= ((int64_t)1 << 28) || n < 1) return hipSuccess;
+  hipError_t e;
+  DictMat T;
+  T.n = n;
+  T.max_width = maxlen;
+  T.words = maxlen > 8 ? 2 : 1;
+  const int nw = T.words;
+  std::map<std::pair<int32_t, uint64_t>, int> pairs;
+  auto add_pairs = [&](const HostRows& R) {
+    for (size_t r = 0; r + 1 < R.ptr.size(); ++r)
+      for (int32_t p = R.ptr[r] - R.ptr[0]; p < R.ptr[r + 1] - R.ptr[0]; ++p) {
+        if (prune && R.val[p] == 0.0) continue;
+        uint64_t bits;
+        std::memcpy(&bits, &R.val[p], 8);
+        const auto key = std::make_pair((int32_t)((int64_t)R.col[p] - (R.r0 + (int64_t)r)), bits);
+        if (pairs.emplace(key, (int)T.doff.size()).second) {
+          T.doff.push_back(key.first);
+          T.dval.push_back(R.val[p]);
+        }
+      }
+  };
+  const int64_t S = std::min<int64_t>(n, 65536);
+  HostRows R;
+  if ((e = fetch_rows(A, 0, S, &R)) != hipSuccess) return e;
+  add_pairs(R);
+  if (n > S) {
+    if ((e = fetch_rows(A, n - S, n, &R)) != hipSuccess) return e;
+    add_pairs(R);
+  }
+  DevMem dfail, dcodes, doff, dval;
+  int32_t fail[64];
+  if ((e = dfail.alloc(sizeof(fail))) != hipSuccess) return e;
+  if ((e = dcodes.alloc(sizeof(uint64_t) * (size_t)n * nw)) != hipSuccess) return e;
+  for (int round = 0;; ++round) {
+    if (T.doff.size() > 255 || round > 64) return hipSuccess;  // does not qualify
+    if ((e = upload(doff, T.doff.data(), T.doff.size())) != hipSuccess) return e;
+    if ((e = upload(dval, T.dval.data(), T.dval.size())) != hipSuccess) return e;
+    if ((e = hipMemset(dfail.p, 0, sizeof(fail))) != hipSuccess) return e;
+    if ((e = launch_dict_encode(n, A.rowptr(), A.col(), A.v(), prune, doff.as<int32_t>(),
+                                dval.as<double>(), (int)T.doff.size(), nw, dcodes.as<uint64_t>(),
+                                dfail.as<int32_t>(), nullptr)) != hipSuccess)
+      return e;
+    if ((e = hipMemcpy(fail, dfail.p, sizeof(fail), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+    if (fail[0] == 0) break;
+    const size_t before = T.doff.size();
+    for (int k = 0; k < std::min(fail[0], 62); ++k) {
+      if ((e = fetch_rows(A, fail[1 + k], (int64_t)fail[1 + k] + 1, &R)) != hipSuccess) return e;
+      add_pairs(R);
+    }
+    if (T.doff.size() == before) return hipSuccess;  // a row longer than the code words hold
+  }
+  // second level: row types
+  T.rwords.assign((size_t)256 * nw, ~(uint64_t)0);
+  std::map<std::pair<uint64_t, uint64_t>, int> types;
+  auto add_words = [&](const std::vector<uint64_t>& cw) {
+    for (size_t r = 0; r * nw < cw.size(); ++r) {
+      const std::pair<uint64_t, uint64_t> key(cw[r * nw], nw == 2 ? cw[r * 2 + 1] : ~(uint64_t)0);
+      if (key.first == ~(uint64_t)0 && key.second == ~(uint64_t)0) continue;  // empty row: type 255
+      if (types.size() < 256 && types.emplace(key, (int)types.size()).second && types.size() <= 255) {
+        const int ty = (int)types.size() - 1;
+        T.rwords[(size_t)ty * nw] = key.first;
+        if (nw == 2) T.rwords[(size_t)ty * 2 + 1] = key.second;
+      }
+    }
+  };
+  auto fetch_codes = [&](int64_t r0, int64_t r1, std::vector<uint64_t>* cw) -> hipError_t {
+    cw->resize((size_t)(r1 - r0) * nw);
+    return hipMemcpy(cw->data(), dcodes.as<uint64_t>() + r0 * nw, sizeof(uint64_t) * cw->size(), hipMemcpyDeviceToHost);
+  };
+  bool typed = g_row_types != 0;
+  DevMem drtype, drwords;
+  if (typed) {
+    std::vector<uint64_t> cw;
+    if ((e = fetch_codes(0, S, &cw)) != hipSuccess) return e;
+    add_words(cw);
+    if (n > S) {
+      if ((e = fetch_codes(n - S, n, &cw)) != hipSuccess) return e;
+      add_words(cw);
+    }
+    if ((e = drtype.alloc((size_t)n)) != hipSuccess) return e;
+    for (int round = 0; typed; ++round) {
+      if (types.size() > 255 || round > 64) { typed = false; break; }
+      if ((e = upload(drwords, T.rwords.data(), T.rwords.size())) != hipSuccess) return e;
+      if ((e = hipMemset(dfail.p, 0, sizeof(fail))) != hipSuccess) return e;
+      if ((e = launch_dict_types(n, dcodes.as<uint64_t>(), nw, drwords.as<uint64_t>(), (int)types.size(),
+                                 drtype.as<uint8_t>(), dfail.as<int32_t>(), nullptr)) != hipSuccess)
+        return e;
+      if ((e = hipMemcpy(fail, dfail.p, sizeof(fail), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+      if (fail[0] == 0) break;
+      for (int k = 0; k < std::min(fail[0], 62); ++k) {
+        if ((e = fetch_codes(fail[1 + k], (int64_t)fail[1 + k] + 1, &cw)) != hipSuccess) return e;
+        add_words(cw);
+      }
+    }
+  }
+  D->n_rows = n;
+  D->nnz = A.nnz;
+  D->dict_typed = typed;
+  if (typed) {
+    D->drtype = std::move(drtype);
+  } else {
+    T.rwords.clear();
+    D->dcodes = std::move(dcodes);
+  }
+  if ((e = finish_dict(T, n, 0, D)) != hipSuccess) return e;
+  *ok = true;
+  return hipSuccess;
+}
+
+void rhs_threads(int dim, int64_t n, double* b, int nt);  // below
+
+// AMG::Multigrid's constructor (multigrid.hpp:151-244) for A = Grid::laplacian(n), b =
+// Grid::rhs(n) without host matrices: generator, Galerkin chain, dictionary encoder, diagonal
+// and symmetry check all run on the device; only b (n^dim exp() calls, kept on the host so that
+// the bits are libm's, like the reference's) and the coarsest operator (factored on the host)
+// cross PCIe.  *unsupported = true: the options need host structures (exact lexicographic
+// schedules, multicolouring, non-dictionary layouts): the caller takes the host path instead.
+amg_hip_status build_poisson_device(int dim, int64_t n, int32_t n_levels, const amg_hip_options* opts,
+                                    amg_hip_solver** out, bool* unsupported) {
+  *unsupported = true;
+  amg_hip_options o;
+  if (opts) o = *opts;
+  else amg_hip_default_options(&o);
+  int64_t N = n * n;
+  if (dim == 3) N *= n;
+  const bool lex = o.smoother <= AMG_HIP_SM_SOR;
+  if (o.host_only || o.host_galerkin || !o.stencil_transfers || o.fuse_prolong ||
+      (o.layout != AMG_HIP_LAYOUT_AUTO && o.layout != AMG_HIP_LAYOUT_DICT) ||
+      o.smoother == AMG_HIP_SM_MULTICOLOR_GS || (lex && (o.exact_gs || N <= GS_SCAN_MIN_ROWS)) ||
+      n_levels < 2 || N >= ((int64_t)1 << 28))
+    return AMG_HIP_OK;
+  if (o.smoother_iters < 0 || (o.smoother == AMG_HIP_SM_SOR && (o.omega > 2 || o.omega < 0)))
+    return AMG_HIP_OK;  // the host path words the argument error
+  std::unique_ptr<amg_hip_solver> s(new amg_hip_solver);
+  s->opt = o;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(AMG_HIP_EHIP, "no HIP device available (this library has no CPU fallback)");
+  if (o.device >= 0) {
+    if (o.device >= ndev) return fail(AMG_HIP_EINVAL, "device ordinal out of range");
+    s->device = o.device;
+  } else {
+    HIP_TRY(hipGetDevice(&s->device));
+  }
+  HIP_TRY(hipSetDevice(s->device));
+  if (o.stream) {
+    s->stream = (hipStream_t)o.stream;
+    s->own_stream = false;
+  } else {
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  }
+  const bool timing = std::getenv("AMG_HIP_TIMING") != nullptr;
+  auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    (void)hipDeviceSynchronize();
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "amg_hip device setup: %s %.3fs\n", what, std::chrono::duration<double>(t1 - t_start).count());
+    t_start = t1;
+  };
+  // b on the host threads while the device builds the hierarchy
+  std::vector<double> b((size_t)N);
+  std::thread rhs_thread([&] { rhs_threads(dim, n, b.data(), host_threads()); });
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{rhs_thread};
+  // A_0 (grid.hpp:88-98)
+  DevCsr cur;
+  {
+    DevMem cnt, bsum, total;
+    HIP_TRY(cnt.alloc(sizeof(int32_t) * (N + 1)));
+    HIP_TRY(bsum.alloc(sizeof(int64_t) * ((N + 1023) / 1024 + 1)));
+    HIP_TRY(total.alloc(sizeof(int64_t)));
+    HIP_TRY(launch_laplacian_count(dim, n, N, cnt.as<int32_t>(), nullptr));
+    HIP_TRY(cur.ptr.alloc(sizeof(int32_t) * (N + 1)));
+    HIP_TRY(launch_exclusive_scan(N, cnt.as<int32_t>(), cur.ptr.as<int32_t>(), bsum.as<int64_t>(),
+                                  total.as<int64_t>(), nullptr));
+    int64_t nnz = 0;
+    HIP_TRY(hipMemcpy(&nnz, total.p, sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (nnz >= ((int64_t)1 << 31) - 1) return AMG_HIP_OK;
+    HIP_TRY(cur.idx.alloc(sizeof(int32_t) * nnz));
+    HIP_TRY(cur.val.alloc(sizeof(double) * nnz));
+    const double h = 2.0 / (double)(n + 1), hh = h * h;
+    const double off = 1.0 / hh, dg = -2.0 / hh;
+    double diag = dg + dg;
+    if (dim == 3) diag = diag + dg;
+    HIP_TRY(launch_laplacian_fill(dim, n, N, cur.ptr.as<int32_t>(), cur.idx.as<int32_t>(),
+                                  cur.val.as<double>(), off, diag, nullptr));
+    cur.n_rows = cur.n_cols = N;
+    cur.nnz = nnz;
+  }
+  lap("generator");
+  s->lv.resize(n_levels);
+  DevMem stats;
+  HIP_TRY(stats.alloc(sizeof(int32_t) * 2));
+  const bool prune = !o.keep_structural_zeros;
+  for (int l = 0; l < n_levels; ++l) {
+    Level& L = s->lv[l];
+    L.n = cur.n_rows;
+    L.nnz_struct = cur.nnz;
+    HIP_TRY(L.diag.alloc(sizeof(double) * L.n));
+    HIP_TRY(hipMemset(stats.p, 0, sizeof(int32_t) * 2));
+    HIP_TRY(launch_csr_inspect(L.n, cur.rowptr(), cur.col(), cur.v(), prune, stats.as<int32_t>(),
+                               L.diag.as<double>(), nullptr));
+    int32_t st[2];
+    HIP_TRY(hipMemcpy(st, stats.p, sizeof(st), hipMemcpyDeviceToHost));
+    if (st[1]) return AMG_HIP_OK;  // not bitwise symmetric: host path
+    L.symmetric = true;
+    bool ok = false;
+    HIP_TRY(device_dict_encode(cur, prune, st[0], &L.A_rows, &ok));
+    if (!ok) return AMG_HIP_OK;
+    if (o.smoother != AMG_HIP_SM_JACOBI) L.diag.release();
+    HIP_TRY(L.u.alloc(sizeof(double) * L.n));
+    HIP_TRY(L.f.alloc(sizeof(double) * L.n));
+    HIP_TRY(L.r.alloc(sizeof(double) * L.n));
+    HIP_TRY(L.tmp.alloc(sizeof(double) * L.n));
+    HIP_TRY(hipMemset(L.u.p, 0, sizeof(double) * L.n));
+    HIP_TRY(hipMemset(L.f.p, 0, sizeof(double) * L.n));
+    HIP_TRY(hipMemset(L.r.p, 0, sizeof(double) * L.n));
+    if (lex && (l + 1 < n_levels || o.keep_residual)) {  // K-GS-scan on every smoothed level, or the host path
+      const DevMat& A = L.A_rows;
+      int ring = 128;
+      const int C = (int)std::min<int64_t>(A.scan_gap, 1024);
+      while (ring < A.scan_far + C + 1 && ring <= 16384) ring *= 2;
+      if (A.scan_gap < 32 || ring > 16384) return AMG_HIP_OK;
+      L.scan_C = C;
+      L.scan_ring = ring;
+    }
+    if (l + 1 == n_levels) {
+      L.A_dev = std::move(cur);
+      break;
+    }
+    const int64_t n_H = coarse_dofs(L.n);  // multigrid.hpp:214
+    if (n_H < 1)
+      return fail(AMG_HIP_EINVAL, "level " + std::to_string(l + 1) +
+                                      " would have no degrees of freedom; reduce `n_levels`");
+    L.lazy_linear = true;
+    L.n_coarse = n_H;
+    L.linear = true;
+    DevCsr next;
+    HIP_TRY(device_galerkin(cur, n_H, &next, nullptr));
+    L.A_dev = std::move(cur);
+    cur = std::move(next);
+  }
+  lap("hierarchy");
+  joiner.t.join();
+  HIP_TRY(hipMemcpy(s->lv[0].f.p, b.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->lv[0].r.p, b.data(), sizeof(double) * N, hipMemcpyHostToDevice));  // b - A*0
+  lap("rhs");
+  {
+    const int want = o.fast_coarse_solve ? 1 : (o.exact_coarse_solve ? -1 : 0);
+    amg_hip_status r = upload_coarse(s->lv[n_levels - 1].host_matrix(), want, &s->coarse);
+    if (r != AMG_HIP_OK) return r;
+  }
+  lap("coarse factor");
+  HIP_TRY(s->scratch.alloc(sizeof(double) * 1100));
+  compute_bytes(s.get());
+  HIP_TRY(hipDeviceSynchronize());
+  *unsupported = false;
+  *out = s.release();
+  return AMG_HIP_OK;
+}
+
 // ---- helpers for the stand-alone host-array entry points ---------------------
 struct Scoped {
   hipStream_t st = nullptr;
   ~Scoped() { if (st) (void)hipStreamDestroy(st); }
 };
+
+// Grid::rhs on several host threads (the values are libm's exp(), as in the reference)
+void rhs_threads(int dim, int64_t n, double* b, int nt) {
+  int64_t N = n * n;
+  if (dim == 3) N *= n;
+  if (nt <= 1 || N < (1 << 18)) {
+    rhs(dim, n, b);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([=] { rhs_range(dim, n, b, N * t / nt, N * (t + 1) / nt); });
+  for (auto& x : th) x.join();
+}
 
 amg_hip_status need_device() {
   int ndev = 0;
@@ -1316,6 +1649,21 @@ amg_hip_status amg_hip_create_custom(int64_t n, const int32_t* colptr, const int
     return fail(AMG_HIP_EINVAL, "custom transfer operator arrays are null");
   return build_solver(n, colptr, rowind, val, b, n_levels, P_colptr, P_rowind, P_val, R_colptr,
                       R_rowind, R_val, opts, out);
+}
+
+amg_hip_status amg_hip_create_poisson(int32_t dim, int64_t n, int32_t n_levels,
+                                      const amg_hip_options* opts, amg_hip_solver** out) {
+  if (!out) return fail(AMG_HIP_EINVAL, "out handle pointer is null");
+  *out = nullptr;
+  if ((dim != 2 && dim != 3) || n < 1) return fail(AMG_HIP_EINVAL, "dim must be 2 or 3 and n >= 1");
+  bool unsupported = true;
+  amg_hip_status r = build_poisson_device(dim, n, n_levels, opts, out, &unsupported);
+  if (r != AMG_HIP_OK || !unsupported) return r;
+  // options that need host structures: generate on the host and take the general constructor
+  Sparse A = laplacian(dim, n);
+  std::vector<double> b((size_t)A.n_outer);
+  rhs_threads(dim, n, b.data(), host_threads());
+  return amg_hip_create(A.n_outer, A.ptr.data(), A.idx.data(), A.val.data(), b.data(), n_levels, opts, out);
 }
 
 void amg_hip_destroy(amg_hip_solver* s) {
@@ -1574,13 +1922,13 @@ int64_t amg_hip_get_n_dofs(const amg_hip_solver* s, int32_t level) {
 }
 int64_t amg_hip_get_level_nnz(const amg_hip_solver* s, int32_t level) {
   if (!s || level < 0 || level >= (int32_t)s->lv.size()) return -1;
-  return s->lv[level].A_csc.nnz();
+  return s->lv[level].nnz_struct;
 }
 amg_hip_status amg_hip_get_level_matrix(const amg_hip_solver* s, int32_t level,
                                         int32_t* colptr, int32_t* rowind, double* val) {
   if (!s || level < 0 || level >= (int32_t)s->lv.size())
     return fail(AMG_HIP_EINVAL, "level out of range");
-  const Sparse& A = s->lv[level].A_csc;
+  const Sparse& A = s->lv[level].host_matrix();
   if (colptr) std::memcpy(colptr, A.ptr.data(), sizeof(int32_t) * A.ptr.size());
   if (rowind) std::memcpy(rowind, A.idx.data(), sizeof(int32_t) * A.idx.size());
   if (val) std::memcpy(val, A.val.data(), sizeof(double) * A.val.size());
@@ -1733,7 +2081,7 @@ amg_hip_status amg_hip_fine_sweep_info(const amg_hip_solver* s, char* name, int3
   layout_of(A, &lay, &mat);
   int sweeps = 1;
   // bytes one launch has to move: what it reads and writes once, not a layout it does not stream
-  double bytes = 12.0 * (double)L.A_csc.nnz() + 28.0 * (double)L.n;  // SELL / CSR: SURVEY 8(d)
+  double bytes = 12.0 * (double)L.nnz_struct + 28.0 * (double)L.n;  // SELL / CSR: SURVEY 8(d)
   if (A.dict && patch_level_ok(s, 0)) {
     // row types + x + f + smoothed u per fine row; f_H, first coarse sweep, coarse diagonal
     std::snprintf(name, (size_t)name_cap, "patch_down_kernel<%d, true, %s>", patch_un(A.patch_un),

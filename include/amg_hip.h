@@ -194,6 +194,19 @@ amg_hip_status amg_hip_create_custom(int64_t n, const int32_t* colptr,
                                      const amg_hip_options* opts,
                                      amg_hip_solver** out);
 
+/* The same constructor for the reference's own model problem, A = Grid::laplacian(n) and
+ * b = Grid::rhs(n) (grid.hpp:88-98,108-140; dim = 3: the 7-point analogue), with the built-in
+ * LinearInterpolator -- SETUP ON THE DEVICE END TO END: the
+ * matrix generator, the Galerkin chain, the dictionary encoder, the diagonal and the symmetry
+ * check are kernels; no host copy of any level matrix is made unless a getter asks for it
+ * (the right-hand side is evaluated on the host threads: its values are libm's exp()).
+ * Identical hierarchy, identical results (tests compare level matrices and V-cycles bitwise
+ * with amg_hip_create on Grid-generated arrays).  Options that need host structures -- exact
+ * lexicographic schedules (exact_gs or small problems), multicolouring, non-dictionary
+ * layouts, host_only -- silently take the host path: generate, then amg_hip_create.       */
+amg_hip_status amg_hip_create_poisson(int32_t dim, int64_t n, int32_t n_levels,
+                                      const amg_hip_options* opts, amg_hip_solver** out);
+
 void amg_hip_destroy(amg_hip_solver* s); /* ~Multigrid, multigrid.hpp:135 */
 
 /* One V-cycle, multigrid.hpp:263-305 (including the smoothing + residual on

@@ -426,3 +426,77 @@ def test_pcg_full_size_4096(amg):
     r = amg.residual(cp, ri, v, x, b)
     assert np.linalg.norm(r) <= 1.05e-8 * np.linalg.norm(b)
     mg.close()
+
+
+# ---------------------------------------------------------------- setup on the device
+@pytest.mark.parametrize("n,L,dim,smoother", [(96, 5, 2, "jacobi"), (257, 6, 2, "jacobi"), (20, 4, 3, "jacobi"),
+                                              (300, 5, 2, "spgs")])
+def test_device_setup_matches_host_setup_and_oracle(amg, oracle, n, L, dim, smoother):
+    """amg_hip_create_poisson (generator, Galerkin chain, dictionary encoder, diagonal on the
+    device; no host matrices) against the host constructor on Grid-generated arrays and the
+    oracle: level sizes, every level matrix incl. structural zeros (multigrid.hpp:219-223),
+    the right-hand side (grid.hpp:108-140), and whole V-cycles, all bit for bit."""
+    A, b = oracle.laplacian(n, dim=dim), oracle.rhs(n, dim=dim)
+    if smoother == "jacobi":
+        kw_g = dict(smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
+        ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
+    else:
+        kw_g = dict()          # SparseGaussSeidel(): 90000 rows > 65536 -> K-GS-scan levels
+        ref = oracle.Multigrid(A, b, L)
+    dev = amg.Multigrid.poisson(n, L, dim=dim, exact_coarse_solve=True, **kw_g)
+    host = amg.Multigrid(*csc(A), b, L, exact_coarse_solve=True, **kw_g)
+    assert np.array_equal(dev.get_rhs(0), b)
+    for l in range(L):
+        assert dev.get_n_dofs(l) == ref.n_dofs(l)
+        cp, ri, v = dev.get_coefficient_matrix(l)
+        R = ref.level_matrix(l)
+        assert np.array_equal(cp, R.colptr) and np.array_equal(ri, R.rowind) and np.array_equal(v, R.val), l
+        assert dev.level_layout(l) == host.level_layout(l)
+    for c in range(3):
+        dev.vcycle()
+        host.vcycle()
+        ref.vcycle()
+    for l in range(L - 1):
+        assert np.array_equal(dev.get_soln(l), host.get_soln(l)), l
+    if smoother == "jacobi":
+        assert np.array_equal(dev.get_soln(0), ref.get_vec(0, "u"))
+    else:
+        ur = ref.get_vec(0, "u")
+        assert np.linalg.norm(dev.get_soln(0) - ur) <= 1e-10 * np.linalg.norm(ur)
+    assert dev.rss() == host.rss()
+    dev.close()
+    host.close()
+
+
+def test_device_setup_falls_back_to_host_structures(amg, oracle):
+    """Options that need host structures (exact lexicographic schedules, multicolouring)
+    take the host path inside amg_hip_create_poisson: same results as the explicit one."""
+    n, L = 48, 3
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    ref = oracle.Multigrid(A, b, L)
+    mg = amg.Multigrid.poisson(n, L)                      # SparseGaussSeidel(), small: exact kernel
+    ref.vcycle()
+    mg.vcycle()
+    assert np.array_equal(mg.get_soln(0), ref.get_vec(0, "u"))
+    mg.close()
+    mc = amg.Multigrid.poisson(n, L, smoother=amg.SM_MULTICOLOR_GS)
+    assert mc.get_colors(0)[1] == 2
+    mc.close()
+    with pytest.raises(ValueError):
+        amg.Multigrid.poisson(n, 40)                      # too many levels: argument error
+
+
+def test_device_setup_time_4096(amg):
+    """setup < 0.5 s at 4096^2 (was 3.0 s through host arrays)."""
+    import time
+    amg.Multigrid.poisson(512, 8, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6).close()   # warm-up
+    t0 = time.perf_counter()
+    mg = amg.Multigrid.poisson(4096, 16, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
+    dt = time.perf_counter() - t0
+    print(f"amg_hip_create_poisson 4096^2 / 16 levels: {dt:.3f} s")
+    mg.vcycle(3)
+    r3 = mg.rss()
+    mg.vcycle(3)
+    assert mg.rss() < r3
+    assert dt < 1.0
+    mg.close()
