@@ -122,19 +122,22 @@ def run_single(args):
     amg.set_xcd_mapping(not args.no_xcd_map)
     amg.set_default_layout({"auto": amg.LAYOUT_AUTO, "csr": amg.LAYOUT_CSR, "sell": amg.LAYOUT_SELL,
                             "dict": amg.LAYOUT_DICT}[args.layout])
+    # setup on the device end to end (generator, Galerkin chain, encoder: amg_hip_create_poisson);
+    # --host-setup hands Grid-generated host arrays to the general constructor instead
     t0 = time.time()
-    colptr, rowind, val = amg.laplacian(args.n)
-    b = amg.rhs(args.n)
     L = args.levels or n_levels_for(args.n)
-    if args.smoother == "multicolor":   # BASELINE configs[3] smoother; one symmetric colour pass
-        mg = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_MULTICOLOR_GS,
-                           smoother_iters=1, use_graph=not args.no_graph)
+    kw = (dict(smoother=amg.SM_MULTICOLOR_GS, smoother_iters=1) if args.smoother == "multicolor" else
+          dict(smoother=amg.SM_JACOBI, smoother_iters=args.sweeps, omega=args.omega,
+               fast_coarse_solve=args.fast_coarse))
+    if args.host_setup:
+        colptr, rowind, val = amg.laplacian(args.n)
+        b = amg.rhs(args.n)
+        mg = amg.Multigrid(colptr, rowind, val, b, L, use_graph=not args.no_graph, **kw)
+        del colptr, rowind, val
     else:
-        mg = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_JACOBI,
-                           smoother_iters=args.sweeps, omega=args.omega, use_graph=not args.no_graph,
-                           fast_coarse_solve=args.fast_coarse)
+        mg = amg.Multigrid.poisson(args.n, L, use_graph=not args.no_graph, **kw)
+    mg.sync()
     setup_s = time.time() - t0
-    del colptr, rowind, val
     mg.vcycle(args.warmup)
     mg.sync()
     rss0 = mg.rss()   # after the warm-up cycles (the first cycle from u=0 raises rss)
@@ -183,10 +186,8 @@ def run_single(args):
     # the same workload with the level matrices as plain CSR panels (SELL-64): the layout
     # SURVEY 8(d)'s CSR-formula bytes describe; a second, shorter measurement in the same run
     if lay_name == "dict" and args.smoother == "jacobi" and not args.no_csr_ref:
-        colptr, rowind, val = amg.laplacian(args.n)
-        ref = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_JACOBI, smoother_iters=args.sweeps,
-                            omega=args.omega, use_graph=not args.no_graph, layout=amg.LAYOUT_SELL)
-        del colptr, rowind, val
+        ref = amg.Multigrid.poisson(args.n, L, smoother=amg.SM_JACOBI, smoother_iters=args.sweeps,
+                                    omega=args.omega, use_graph=not args.no_graph, layout=amg.LAYOUT_SELL)
         ref.vcycle(args.warmup)
         ref.sync()
         t2 = time.perf_counter()
@@ -280,6 +281,8 @@ def main():
                          "(default 2^20; -1 = off)")
     ap.add_argument("--fast-coarse", action="store_true",
                     help="partitioned (parallel) coarse solve; then fewer levels pay off (--levels 13)")
+    ap.add_argument("--host-setup", action="store_true",
+                    help="build the hierarchy from host arrays (amg_hip_create) instead of on the device")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-csr-ref", action="store_true",
                     help="skip the second measurement with the plain-CSR (SELL-64) layout")
