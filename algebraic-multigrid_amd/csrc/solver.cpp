@@ -1506,11 +1506,49 @@ amg_hip_status build_poisson_device(int dim, int64_t n, int32_t n_levels, const 
                                L.diag.as<double>(), nullptr));
     int32_t st[2];
     HIP_TRY(hipMemcpy(st, stats.p, sizeof(st), hipMemcpyDeviceToHost));
-    if (st[1]) return AMG_HIP_OK;  // not bitwise symmetric: host path
-    L.symmetric = true;
+    L.symmetric = st[1] == 0;
     bool ok = false;
-    HIP_TRY(device_dict_encode(cur, prune, st[0], &L.A_rows, &ok));
-    if (!ok) return AMG_HIP_OK;
+    if (!L.symmetric) {
+      // Galerkin sums of a deep 3-D level can differ in the last bit between (i, j) and (j, i):
+      // the smoothers then walk the columns of A (smoother.hpp:101-117), the residual its rows.
+      // Both forms of this one level are made on the host (transpose) and uploaded; the chain
+      // itself stays on the device.
+      if (lex) return AMG_HIP_OK;
+      if (timing) std::fprintf(stderr, "amg_hip device setup: level %d (%lld rows) not bitwise symmetric -> rows and columns uploaded separately\n",
+                               l, (long long)L.n);
+      Sparse H;
+      H.n_outer = H.n_inner = L.n;
+      H.ptr.resize((size_t)L.n + 1);
+      H.idx.resize((size_t)cur.nnz);
+      H.val.resize((size_t)cur.nnz);
+      HIP_TRY(hipMemcpy(H.ptr.data(), cur.ptr.p, sizeof(int32_t) * H.ptr.size(), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(H.idx.data(), cur.idx.p, sizeof(int32_t) * H.idx.size(), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(H.val.data(), cur.val.p, sizeof(double) * H.val.size(), hipMemcpyDeviceToHost));
+      HIP_TRY(upload_mat_pruned(H, o.layout, prune, &L.A_rows));       // H = CSR(A)
+      L.A_csc = transpose(H);                                           // CSC(A)
+      HIP_TRY(upload_mat_pruned(L.A_csc, o.layout, prune, &L.A_cols_own));
+      ok = true;
+    } else {
+      HIP_TRY(device_dict_encode(cur, prune, st[0], &L.A_rows, &ok));
+    }
+    if (!ok) {
+      // this level does not qualify for the dictionary (rows of more than 16 entries on the
+      // deep 3-D levels, more than 255 pairs): its CSR arrays go to the host once and take
+      // the general upload (SELL-64 / CSR panels); the chain itself stays on the device
+      if (timing) std::fprintf(stderr, "amg_hip device setup: level %d (%lld rows, longest row %d) -> panel layout\n",
+                               l, (long long)L.n, (int)st[0]);
+      L.A_dev.n_rows = 0;
+      Sparse H;
+      H.n_outer = H.n_inner = L.n;
+      H.ptr.resize((size_t)L.n + 1);
+      H.idx.resize((size_t)cur.nnz);
+      H.val.resize((size_t)cur.nnz);
+      HIP_TRY(hipMemcpy(H.ptr.data(), cur.ptr.p, sizeof(int32_t) * H.ptr.size(), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(H.idx.data(), cur.idx.p, sizeof(int32_t) * H.idx.size(), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(H.val.data(), cur.val.p, sizeof(double) * H.val.size(), hipMemcpyDeviceToHost));
+      HIP_TRY(upload_mat_pruned(H, AMG_HIP_LAYOUT_SELL, prune, &L.A_rows));
+      L.A_csc = std::move(H);  // symmetric: the CSR arrays are the CSC arrays
+    }
     if (o.smoother != AMG_HIP_SM_JACOBI) L.diag.release();
     HIP_TRY(L.u.alloc(sizeof(double) * L.n));
     HIP_TRY(L.f.alloc(sizeof(double) * L.n));
@@ -1529,7 +1567,7 @@ amg_hip_status build_poisson_device(int dim, int64_t n, int32_t n_levels, const 
       L.scan_ring = ring;
     }
     if (l + 1 == n_levels) {
-      L.A_dev = std::move(cur);
+      if (L.A_csc.ptr.empty()) L.A_dev = std::move(cur);
       break;
     }
     const int64_t n_H = coarse_dofs(L.n);  // multigrid.hpp:214
@@ -1540,8 +1578,15 @@ amg_hip_status build_poisson_device(int dim, int64_t n, int32_t n_levels, const 
     L.n_coarse = n_H;
     L.linear = true;
     DevCsr next;
-    HIP_TRY(device_galerkin(cur, n_H, &next, nullptr));
-    L.A_dev = std::move(cur);
+    {
+      const hipError_t ge = device_galerkin(cur, n_H, &next, nullptr);
+      if (ge == hipErrorInvalidValue) {  // an intermediate product beyond int32 indices: host path
+        if (timing) std::fprintf(stderr, "amg_hip device setup: Galerkin product of level %d exceeds int32 indexing -> host path\n", l);
+        return AMG_HIP_OK;
+      }
+      HIP_TRY(ge);
+    }
+    if (L.A_csc.ptr.empty()) L.A_dev = std::move(cur);
     cur = std::move(next);
   }
   lap("hierarchy");
