@@ -947,6 +947,23 @@ def bench(args):
 
     dog = TransportWatchdog(rank, args.comm_timeout, stash)
 
+    # Agglomeration threshold above the fine level: nothing is distributed, every rank runs the
+    # whole (fused, K-Patch) single-GPU cycle redundantly.  With host-driven exchanges
+    # (~80 us each, ~7 per level and cycle) that is the faster configuration whenever a level
+    # takes one GPU less than its exchanges cost -- at 4096^2 always (level 0: 390 us); it is
+    # timed like any other candidate and reported as "replicated" when it wins.
+    if dv.n_dist and args.comm in ("auto", "p2p"):
+        dvr = DistributedVcycle(hier, b, be, rank, world, omega=args.omega, sweeps=args.sweeps,
+                                dist_min_rows=1 << 62, host_staged=rehearsal, comm="p2p")
+        res = timed(dvr)
+        if res[1] == results["p2p"][1] and res[2] == results["p2p"][2]:
+            results["replicated"] = res
+            notes["replicated"] = "ok"
+        else:
+            notes["replicated"] = "did not reproduce the sharded result; discarded"
+        notes["replicated_distributed_levels"] = dvr.n_dist
+        dvr.close()
+
     if dv.n_dist and args.comm != "p2p":
         import json as _json
         stash["json"] = _json.dumps(_result_line(args, world, L, dv, results, "p2p", {"note": "alternative exchange hung"},
