@@ -66,6 +66,10 @@ def _worker(rank, world, port, n, L, cycles, agg, sweeps, omega, out_dir, use_pr
         dv.vcycle()
         rss.append(dv.rss())
     u = dv.gather_solution()
+    # partition-independent fingerprint (what bench.py --gpus N compares between transports and
+    # between the sharded and the replicated configuration): must equal the gathered vector's
+    chk = dv.solution_checksum()
+    assert chk == int(np.ascontiguousarray(u).view(np.int64).sum(dtype=np.int64)), "checksum"
     if hasattr(dv, "timed_out"):
         assert not dv.timed_out(), "a bounded spin of the in-kernel halo protocol gave up"
     if rank == 0:
