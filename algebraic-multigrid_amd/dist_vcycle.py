@@ -1037,7 +1037,8 @@ def bench(args):
         sweep_bytes = 12.0 * D.A.nnz + 28.0 * n
     # nothing distributed (replicated, or the threshold left no level to shard): every rank runs
     # the single-GPU solver, and the dominant kernel is that solver's (same object as at N = 1)
-    whole = dvr if (best == "replicated" and dvr is not None) else (dv if dv.n_dist == 0 else None)
+    best_nd = dv.n_dist if best == "p2p" else notes.get(best + "_distributed_levels")
+    whole = (dv if dv.n_dist == 0 else dvr) if best_nd == 0 else None
     roof_whole = None
     if whole is not None and hasattr(whole.tail, "mg"):
         from bench import fine_sweep_roofline
