@@ -970,7 +970,7 @@ def bench(args):
     # (~80 us each, ~7 per level and cycle) that is the faster configuration whenever a level
     # takes one GPU less than its exchanges cost -- at 4096^2 always (level 0: 390 us); it is
     # timed like any other candidate and reported as "replicated" when it wins.
-    if dv.n_dist and args.comm in ("auto", "p2p"):
+    if dv.n_dist and args.comm in ("safe", "auto", "p2p"):
         dvr = DistributedVcycle(hier, b, be, rank, world, omega=args.omega, sweeps=args.sweeps,
                                 dist_min_rows=1 << 62, host_staged=rehearsal, comm="p2p")
         res = timed(dvr)
@@ -981,7 +981,7 @@ def bench(args):
             notes["replicated"] = "did not reproduce the sharded result; discarded"
         notes["replicated_distributed_levels"] = dvr.n_dist
 
-    if dv.n_dist and args.comm != "p2p":
+    if dv.n_dist and args.comm not in ("p2p", "safe"):
         import json as _json
         stash["json"] = _json.dumps(_result_line(args, world, L, dv, results, "p2p", {"note": "alternative exchange hung"},
                                                  rehearsal, None, None, t0)) if rank == 0 else None

@@ -290,11 +290,14 @@ def main():
                     help="grid of the CPU baseline sample (0 = the benchmarked --grid itself)")
     ap.add_argument("--cpu-cycles", type=int, default=3)
     ap.add_argument("--profile-launches", type=int, default=40)
-    ap.add_argument("--comm", choices=["auto", "p2p", "ipc", "graph"], default="auto",
-                    help="multi-GPU halo exchange: p2p = torch.distributed isend/irecv (RCCL); ipc = "
-                         "direct hipIpc pushes with stream memory ops; graph = pushes + flags as "
-                         "kernels, one hipGraph per rank; auto = time all, keep the fastest that "
-                         "reproduces the p2p result bit for bit")
+    ap.add_argument("--comm", choices=["safe", "auto", "p2p", "ipc", "graph"], default="safe",
+                    help="multi-GPU halo exchange.  safe (default) = the two configurations that "
+                         "cannot hang: p2p (torch.distributed isend/irecv over RCCL) and replicated "
+                         "(nothing distributed); the faster one is reported.  auto = additionally "
+                         "ipc (hipIpc pushes + stream memory ops) and graph (pushes + flags as "
+                         "kernels, one hipGraph per rank): experimental, never run on real xGMI "
+                         "links; bounded by a watchdog that exits with status 3 when one hangs.  "
+                         "Every candidate must reproduce the p2p result bit for bit")
     ap.add_argument("--dist-min-rows-ipc", type=int, default=5000000)
     ap.add_argument("--dist-min-rows-graph", type=int, default=250000)
     ap.add_argument("--comm-timeout", type=float, default=180.0,
