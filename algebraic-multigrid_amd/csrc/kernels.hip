@@ -908,8 +908,8 @@ constexpr int PATCH_TW = 64;                 // columns of a patch (output)
 constexpr int PATCH_TH = 42;                 // lines of a patch (output)
 constexpr int PATCH_EH = PATCH_TH + 6;       // lines held, 3 rings
 constexpr int PATCH_EC = PATCH_TW + 8;       // columns held: [-4, TW + 4)
-constexpr int PATCH_NT = 576;                // threads = 8 lines of 72 cells
-constexpr int PATCH_K = PATCH_EH * PATCH_EC / PATCH_NT;  // cells per thread (6), 8 lines apart
+constexpr int PATCH_NT = 576;                // threads = 8 line groups x 72 columns
+constexpr int PATCH_K = PATCH_EH * PATCH_EC / PATCH_NT;  // cells per thread: 6 consecutive lines
 constexpr int PATCH_BUF = (PATCH_EH + 2) * PATCH_EC;     // + one guard line above and below
 constexpr int PATCH_MAXTAB = 192;            // table capacity: (types + 1) x slots
 static_assert(PATCH_EH * PATCH_EC == PATCH_K * PATCH_NT && PATCH_NT % PATCH_EC == 0, "patch geometry");
@@ -917,9 +917,11 @@ static_assert(PATCH_EH * PATCH_EC == PATCH_K * PATCH_NT && PATCH_NT % PATCH_EC =
 struct PatchJ { double a, d; };              // off-diagonal value (else +0.0), diagonal value (else +0.0)
 struct PatchR { double a; int32_t loff, ok; };  // value, LDS offset, slot in use
 
-// The PATCH_K cells one thread owns: column li of lines lj0, lj0 + 8, ...; cell k sits at LDS
-// index cell0 + k * PATCH_NT and is flat row row0 + 8 k m.  Adjacent lanes own adjacent cells
-// (conflict-free 8-byte LDS accesses, coalesced global ones).
+// The PATCH_K cells one thread owns: column li of the consecutive lines lj0 .. lj0 + 5; cell k
+// sits at LDS index cell0 + k * PATCH_EC and is flat row row0 + k m.  Adjacent lanes own
+// adjacent columns (conflict-free 8-byte LDS accesses, coalesced global ones), and a thread's
+// cells are vertical neighbours, so the wave-uniform path walks them with a sliding 3 x 3
+// register window: 3 LDS reads per cell instead of one per matrix entry.
 struct PatchCells {
   int cell0, row0, lj0, li;
   double f[PATCH_K];
@@ -935,58 +937,86 @@ struct PatchCells {
 //   utabd: per type aj[UN] (off-diagonal values, +0.0 elsewhere), ar[UN] (values), diag
 //   utabi: per type lo[UN] (LDS offsets), jmask (slots with an off-diagonal entry), rmask
 //          (slots in use)
-template <int UN>
+// slot s = (dj + 1) * 3 + (di + 1) of the 3 x 3 neighbourhood = ascending column offset
+// (-m-1, -m, -m+1, -1, 0, +1, m-1, m, m+1): walking the slots in order IS the reference's
+// ascending-column summation order (smoother.hpp:101-117).
+//   utabd: per type wj[9] (off-diagonal values, +0.0 where there is no entry and on the
+//          diagonal), wr[9] (values, +0.0 where there is no entry), diag
+//   utabi: per type rmask (slots in use), corners (1 when a corner slot 0, 2, 6, 8 is in use)
 struct PatchU {
-  double aj[UN], ar[UN], diag;
-  int lo[UN];
-  uint32_t jmask, rmask;
+  double wj[9], wr[9], diag;
+  uint32_t rmask, corners;
 };
-template <int UN>
-__device__ __forceinline__ void patch_load_u(PatchU<UN>& U, uint32_t tu,
-                                             const double* __restrict__ utabd,
+__device__ __forceinline__ void patch_load_u(PatchU& U, uint32_t tu, const double* __restrict__ utabd,
                                              const int32_t* __restrict__ utabi) {
-  const double* d = utabd + (size_t)tu * (2 * UN + 1);
-  const int32_t* i = utabi + (size_t)tu * (UN + 2);
+  const double* d = utabd + (size_t)tu * 19;
+  const int32_t* i = utabi + (size_t)tu * 2;
 #pragma unroll
-  for (int e = 0; e < UN; ++e) {
-    U.aj[e] = d[e];
-    U.ar[e] = d[UN + e];
-    U.lo[e] = i[e];
+  for (int e = 0; e < 9; ++e) {
+    U.wj[e] = d[e];
+    U.wr[e] = d[9 + e];
   }
-  U.diag = d[2 * UN];
-  U.jmask = (uint32_t)i[UN];
-  U.rmask = (uint32_t)i[UN + 1];
+  U.diag = d[18];
+  U.rmask = (uint32_t)i[0];
+  U.corners = (uint32_t)i[1];
 }
-// Uniform-type evaluation of one cell.  at[e] = cell0 + lo[e] (per lane, computed once per
-// workgroup), koff = compile-time offset of the cell and buffer.  Slots whose value is +0.0
-// for this operation (unused, or the diagonal in a Jacobi sweep) are skipped: adding or
-// subtracting (+0.0) x leaves the accumulator's bits alone for finite x (see dict_rows), and
-// the diagonal value is the type's (0.0 + ... + d + 0.0 ... = d exactly).
-template <int UN, bool RESID>
-__device__ __forceinline__ double patch_eval_u(const double* buf, const int (&at)[UN], int cell,
-                                               int koff, const PatchU<UN>& U, double fi,
-                                               double omega) {
-  constexpr uint32_t FULL = (1u << UN) - 1u;
-  if (RESID) {
-    double acc = fi;
-    if (U.rmask == FULL) {
+// Uniform-type evaluation of the thread's PATCH_K vertically consecutive cells with a sliding
+// window: w[r][c] = value of line (k - 1 + r), column (li - 1 + c).  Slots that hold no entry
+// have weight +0.0: adding (+0.0) x leaves a Jacobi accumulator's bits alone for finite x (see
+// dict_rows); the residual selects them away.  CORNERS = false: the four corner slots are
+// not even read (5-point level).
+template <bool RESID, bool CORNERS>
+__device__ __forceinline__ void patch_eval_u(const double* buf, int cell0, const PatchU& U,
+                                             const double (&f)[PATCH_K], double omega,
+                                             double (&res)[PATCH_K]) {
+  const double* p = buf + cell0 - PATCH_EC;  // line above the first cell
+  double w[3][3];
 #pragma unroll
-      for (int e = 0; e < UN; ++e) acc -= U.ar[e] * buf[at[e] + koff];
-    } else {
+  for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int e = 0; e < UN; ++e)
-        if ((U.rmask >> e) & 1u) acc -= U.ar[e] * buf[at[e] + koff];
+    for (int c = 0; c < 3; ++c) w[r][c] = (CORNERS || c == 1 || r == 1) ? p[r * PATCH_EC + c - 1] : 0.0;
+#pragma unroll
+  for (int k = 0; k < PATCH_K; ++k) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      w[2][c] = (CORNERS || c == 1) ? p[(k + 2) * PATCH_EC + c - 1] : 0.0;
+    if (!CORNERS) {  // left / right of line k + 1 become the middle row's of the next cell
+      w[2][0] = p[(k + 2) * PATCH_EC - 1];
+      w[2][2] = p[(k + 2) * PATCH_EC + 1];
     }
-    return acc;
-  }
-  const double xi = buf[cell + koff];
-  double acc = 0.0;
+    const double xi = w[1][1];
+    if (RESID) {
+      double acc = f[k];
 #pragma unroll
-  for (int e = 0; e < UN; ++e)
-    if ((U.jmask >> e) & 1u) acc += U.aj[e] * buf[at[e] + koff];
-  if (U.diag == 0.0) return xi;
-  const double q = (fi - acc) / U.diag;  // smoother.hpp:136
-  return xi + omega * (q - xi);
+      for (int s9 = 0; s9 < 9; ++s9) {
+        const int r = s9 / 3, c = s9 % 3;
+        if (!CORNERS && r != 1 && c != 1) continue;
+        double t = U.wr[s9] * w[r][c];
+        t = ((U.rmask >> s9) & 1u) ? t : 0.0;
+        acc -= t;
+      }
+      res[k] = acc;
+    } else {
+      double acc = 0.0;
+#pragma unroll
+      for (int s9 = 0; s9 < 9; ++s9) {
+        const int r = s9 / 3, c = s9 % 3;
+        if (s9 == 4 || (!CORNERS && r != 1 && c != 1)) continue;
+        acc += U.wj[s9] * w[r][c];
+      }
+      if (U.diag == 0.0) {
+        res[k] = xi;
+      } else {
+        const double q = (f[k] - acc) / U.diag;  // smoother.hpp:136
+        res[k] = xi + omega * (q - xi);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      w[0][c] = w[1][c];
+      w[1][c] = w[2][c];
+    }
+  }
 }
 
 // Row arithmetic of dict_rows, per-lane table entries from the LDS copy (mixed row types:
@@ -1044,39 +1074,37 @@ __device__ __forceinline__ double patch_eval(const double* buf, int cell, uint32
 // restriction reads).  out (optional): rows of the patch proper also go to global memory.
 template <int UN, bool RESID, bool NT, bool ZERO>
 __device__ __forceinline__ void patch_stage(const PatchCells& pc, int m, int ntypes, double* buf,
-                                            const PatchU<UN>& U, const int (&at)[UN],
-                                            const PatchJ* tabJ, const PatchR* tabR, double omega,
-                                            int l0, int l1, int c0, int c1, double* out) {
+                                            const PatchU& U, const PatchJ* tabJ, const PatchR* tabR,
+                                            double omega, int l0, int l1, int c0, int c1, double* out) {
   const bool inc = pc.li >= c0 && pc.li < c1;
   double res[PATCH_K];
   bool did[PATCH_K], inr[PATCH_K];
 #pragma unroll
   for (int k = 0; k < PATCH_K; ++k) {
-    const int lj = pc.lj0 + 8 * k;
+    const int lj = pc.lj0 + k;
     inr[k] = inc && lj >= l0 && lj < l1;
     did[k] = inr[k] && pc.live[k];
   }
   if (pc.uniform) {
     // interior of the level: one row type for the whole wave; cells outside the region are
     // evaluated with it too (their reads stay inside the guard lines) and dropped
-#pragma unroll
-    for (int k = 0; k < PATCH_K; ++k)
-      res[k] = patch_eval_u<UN, RESID>(buf, at, pc.cell0, k * PATCH_NT, U, pc.f[k], omega);
+    if (U.corners) patch_eval_u<RESID, true>(buf, pc.cell0, U, pc.f, omega, res);
+    else patch_eval_u<RESID, false>(buf, pc.cell0, U, pc.f, omega, res);
   } else {
 #pragma unroll
     for (int k = 0; k < PATCH_K; ++k)
-      res[k] = patch_eval<UN, RESID>(buf, pc.cell0 + k * PATCH_NT,
+      res[k] = patch_eval<UN, RESID>(buf, pc.cell0 + k * PATCH_EC,
                                      did[k] ? pc.ty[k] : (uint32_t)ntypes, tabJ, tabR, pc.f[k], omega);
   }
   lds_barrier();  // everybody has read the old values
   const bool outc = out != nullptr && pc.li >= 0 && pc.li < PATCH_TW;
 #pragma unroll
   for (int k = 0; k < PATCH_K; ++k) {
-    if (did[k]) buf[pc.cell0 + k * PATCH_NT] = res[k];
-    else if (ZERO && inr[k]) buf[pc.cell0 + k * PATCH_NT] = 0.0;
-    const int lj = pc.lj0 + 8 * k;
+    if (did[k]) buf[pc.cell0 + k * PATCH_EC] = res[k];
+    else if (ZERO && inr[k]) buf[pc.cell0 + k * PATCH_EC] = 0.0;
+    const int lj = pc.lj0 + k;
     if (outc && did[k] && lj >= 0 && lj < PATCH_TH) {
-      double* op = out + (pc.row0 + 8 * k * m);
+      double* op = out + (pc.row0 + k * m);
       if (NT) __builtin_nontemporal_store(res[k], op);
       else *op = res[k];
     }
@@ -1090,7 +1118,8 @@ __device__ __forceinline__ void patch_load(PatchCells& pc, int n, int m, int j0,
                                            const double* __restrict__ f,
                                            const uint8_t* __restrict__ rtype, int ntypes,
                                            const double* __restrict__ uH, int nH, double* buf) {
-  const int le = (int)threadIdx.x / PATCH_EC, col = (int)threadIdx.x - le * PATCH_EC;
+  const int g = (int)threadIdx.x / PATCH_EC, col = (int)threadIdx.x - g * PATCH_EC;
+  const int le = g * PATCH_K;            // first of the thread's PATCH_K consecutive lines
   pc.lj0 = le - 3;
   pc.li = col - 4;
   pc.cell0 = (le + 1) * PATCH_EC + col;  // + 1: guard line
@@ -1100,7 +1129,7 @@ __device__ __forceinline__ void patch_load(PatchCells& pc, int n, int m, int j0,
   double xv[PATCH_K];
 #pragma unroll
   for (int k = 0; k < PATCH_K; ++k) {
-    const int64_t r64 = r0 + (int64_t)8 * k * m;
+    const int64_t r64 = r0 + (int64_t)k * m;
     pc.live[k] = r64 >= 0 && r64 < (int64_t)n;
     const int row = pc.live[k] ? (int)r64 : 0;
     xv[k] = x[row];
@@ -1109,7 +1138,7 @@ __device__ __forceinline__ void patch_load(PatchCells& pc, int n, int m, int j0,
   }
 #pragma unroll
   for (int k = 0; k < PATCH_K; ++k) {
-    const int row = pc.row0 + 8 * k * m;
+    const int row = pc.row0 + k * m;
     double x0 = pc.live[k] ? xv[k] : 0.0;
     if (PROLONG) {  // linear_prolong_add_kernel, same guards and order, written with selects
       const int j = pc.live[k] ? (row >> 1) : 0;
@@ -1122,7 +1151,7 @@ __device__ __forceinline__ void patch_load(PatchCells& pc, int n, int m, int j0,
       t = b_ok ? t + (odd ? 1.0 : 0.5) * b : t;
       x0 = pc.live[k] ? x0 + t : x0;
     }
-    buf[pc.cell0 + k * PATCH_NT] = x0;
+    buf[pc.cell0 + k * PATCH_EC] = x0;
     const uint32_t nty = (uint32_t)ntypes;
     pc.ty[k] = (pc.live[k] && pc.ty[k] < nty) ? pc.ty[k] : nty;  // 255 = empty row -> absent row
     pc.f[k] = pc.live[k] ? pc.f[k] : 0.0;
@@ -1157,18 +1186,14 @@ __device__ __forceinline__ void patch_clear_guards(double* buf) {
     buf[t < PATCH_EC ? t : PATCH_BUF - 2 * PATCH_EC + t] = 0.0;
 }
 
-// common prologue: tables, guards, the uniform type's table and the per-lane gather bases
-template <int UN>
+// common prologue: tables, guards and the uniform type's table (scalar loads)
 __device__ __forceinline__ void patch_prologue(const PatchCells& pc, double* buf, PatchJ* tabJ,
                                                PatchR* tabR, const double* __restrict__ ptab,
                                                int nent, const double* __restrict__ utabd,
-                                               const int32_t* __restrict__ utabi, PatchU<UN>& U,
-                                               int (&at)[UN]) {
+                                               const int32_t* __restrict__ utabi, PatchU& U) {
   patch_stage_tables(tabJ, tabR, ptab, nent);
   patch_clear_guards(buf);
-  patch_load_u<UN>(U, pc.uniform ? pc.tu : 0u, utabd, utabi);
-#pragma unroll
-  for (int e = 0; e < UN; ++e) at[e] = pc.cell0 + U.lo[e];
+  patch_load_u(U, pc.uniform ? pc.tu : 0u, utabd, utabi);
 }
 
 // FIRST: the input is the level's u and both pre-sweeps run here (level 0); else the input
@@ -1187,21 +1212,20 @@ __global__ __launch_bounds__(PATCH_NT) void patch_down_kernel(
   const int py = tile / px_count, px = tile - py * px_count;
   const int j0 = py * PATCH_TH, i0 = px * PATCH_TW;
   PatchCells pc;
-  PatchU<UN> U;
-  int at[UN];
+  PatchU U;
   patch_load<false>(pc, n, m, j0, i0, x, f, rtype, ntypes, nullptr, 0, buf);
-  patch_prologue<UN>(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U, at);
+  patch_prologue(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U);
   lds_barrier();
   if (FIRST) {
-    patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, -2, PATCH_TH + 2, -2,
+    patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -2, PATCH_TH + 2, -2,
                                       PATCH_TW + 3, nullptr);
     lds_barrier();
   }
-  patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
+  patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
                                     PATCH_TW + 2, u_out);
   lds_barrier();
   // residual; rows outside the matrix read as 0.0 for the restriction (ZERO)
-  patch_stage<UN, true, NT, true>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW + 1,
+  patch_stage<UN, true, NT, true>(pc, m, ntypes, buf, U, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW + 1,
                                   r_out);
   lds_barrier();
   const double* rsb = buf;
@@ -1236,15 +1260,14 @@ __global__ __launch_bounds__(PATCH_NT) void patch_up_kernel(
   const int py = tile / px_count, px = tile - py * px_count;
   const int j0 = py * PATCH_TH, i0 = px * PATCH_TW;
   PatchCells pc;
-  PatchU<UN> U;
-  int at[UN];
+  PatchU U;
   patch_load<true>(pc, n, m, j0, i0, x, f, rtype, ntypes, uH, nH, buf);
-  patch_prologue<UN>(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U, at);
+  patch_prologue(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U);
   lds_barrier();
-  patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
+  patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
                                     PATCH_TW + 1, nullptr);
   lds_barrier();
-  patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, at, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW,
+  patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW,
                                     u_out);
 }
 

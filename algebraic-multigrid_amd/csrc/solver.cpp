@@ -340,27 +340,28 @@ hipError_t finish_dict(const DictMat& T, int64_t n, int64_t diag_shift, DevMat* 
     std::vector<double> tab;
     if (build_patch_table(T, n, &D->patch_m, &D->patch_un, &D->patch_ntypes, &tab)) {
       if ((e = upload(D->patch_tab, tab.data(), tab.size())) != hipSuccess) return e;
-      // per-type form for the wave-uniform path (+ the all-absent type `ntypes`)
-      const int un = D->patch_un, nty = D->patch_ntypes;
-      std::vector<double> ud((size_t)(nty + 1) * (2 * un + 1), 0.0);
-      std::vector<int32_t> ui((size_t)(nty + 1) * (un + 2), 0);
+      // per-type 3 x 3 slot form for the wave-uniform path (+ the all-absent type `ntypes`):
+      // slot = (dj + 1) * 3 + (di + 1) = ascending column offset
+      const int un = D->patch_un, nty = D->patch_ntypes, pitch = patch_lds_pitch();
+      std::vector<double> ud((size_t)(nty + 1) * 19, 0.0);
+      std::vector<int32_t> ui((size_t)(nty + 1) * 2, 0);
       for (int t = 0; t < nty; ++t) {
         double diag = 0.0;
-        uint32_t jm = 0, rm = 0;
+        uint32_t rm = 0;
         for (int k = 0; k < un; ++k) {
           const double* q = &tab[((size_t)t * un + k) * 4];
-          const bool used = q[3] > -1.0e8;
-          ud[(size_t)t * (2 * un + 1) + k] = q[0];
-          ud[(size_t)t * (2 * un + 1) + un + k] = q[2];
+          if (!(q[3] > -1.0e8)) continue;
+          const int lo = (int)q[3];
+          const int dj = lo > pitch / 2 ? 1 : (lo < -pitch / 2 ? -1 : 0), di = lo - dj * pitch;
+          const int slot = (dj + 1) * 3 + (di + 1);
+          ud[(size_t)t * 19 + slot] = q[0];
+          ud[(size_t)t * 19 + 9 + slot] = q[2];
           diag += q[1];  // dict_rows' order: +0.0 except the diagonal slot
-          ui[(size_t)t * (un + 2) + k] = used ? (int32_t)q[3] : 0;
-          // slots whose Jacobi value is +0.0 (unused, diagonal, pruned) add nothing
-          if (used && q[0] != 0.0) jm |= 1u << k;
-          if (used) rm |= 1u << k;
+          rm |= 1u << slot;
         }
-        ud[(size_t)t * (2 * un + 1) + 2 * un] = diag;
-        ui[(size_t)t * (un + 2) + un] = (int32_t)jm;
-        ui[(size_t)t * (un + 2) + un + 1] = (int32_t)rm;
+        ud[(size_t)t * 19 + 18] = diag;
+        ui[(size_t)t * 2] = (int32_t)rm;
+        ui[(size_t)t * 2 + 1] = (rm & 0x145u) ? 1 : 0;  // corner slots 0, 2, 6, 8
       }
       if ((e = upload(D->patch_utabd, ud.data(), ud.size())) != hipSuccess) return e;
       if ((e = upload(D->patch_utabi, ui.data(), ui.size())) != hipSuccess) return e;
