@@ -1893,6 +1893,8 @@ hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, 
   return hipErrorInvalidValue;
 }
 
+static int g_scan_typed = 1;
+void set_scan_typed(int on) { g_scan_typed = on ? 1 : 0; }
 // --------------------------------------------------------------- K-GS-scan ---
 // Lexicographic Gauss-Seidel at size (smoother.hpp:148-174).  On the reference's Galerkin
 // levels row k of a forward sweep needs the NEW values of k-1 (the flat-index chain, SURVEY
@@ -2128,6 +2130,187 @@ __global__ __launch_bounds__(1024) void gs_scan_kernel(
   }
 }
 
+// ---- row-typed matrices: everything that does not depend on new values moves to the pre-pass
+// The chain coefficient, the diagonal and the weights of the new-side entries are properties
+// of the row TYPE.  The pre-pass therefore leaves ONE number per row,
+//   P_k = (b_k - s_old_k) / a_kk          (SOR: u_k + omega (that - u_k); rows that SpGS leaves
+//                                          alone: u_k, with all weights 0),
+// and the serial kernel evaluates  c_k = P_k - sum_e w_e u_new[k + off_e],  q_k = Q  with
+// w_e = a_e / a_kk (x omega), Q = -a_chain / a_kk (x omega) from a per-type LDS table: no code
+// words, no division and at most SCAN_NEW ring reads on the serial path.
+constexpr int SCAN_NEW = 4;  // new-side entries other than the chain, per row type (2-D: 3)
+// per-type table as three LDS arrays: tq[256], tw[256 * SCAN_NEW], toff[256 * SCAN_NEW];
+// thread t < 256 builds the entry of type t from its code words (type 255 / unused: zeros)
+template <int WORDS, int UN>
+__device__ __forceinline__ void scan_build_types(double* tq, double* tw, int32_t* toff,
+                                                 const ScanEntry* tab, const uint64_t* wtab,
+                                                 int backward, int mode, double omega) {
+  const int t = threadIdx.x;
+  if (t >= 256) return;
+  const int chain = backward ? 1 : -1;
+  double diag = 0.0, achain = 0.0;
+  for (int e = 0; e < UN; ++e) {
+    const uint32_t code = (uint32_t)(wtab[t * WORDS + (e >> 3)] >> (8 * (e & 7))) & 0xFFu;
+    if (code != 0xFFu) {
+      const ScanEntry en = tab[code];
+      if (en.off == 0) diag = en.v;
+      if (en.off == chain) achain = en.v;
+    }
+  }
+  const bool frozen = mode == 0 && diag == 0.0;  // smoother.hpp:134-137
+  const double sc = mode == 2 ? omega : 1.0;
+  for (int e = 0; e < SCAN_NEW; ++e) {
+    tw[t * SCAN_NEW + e] = 0.0;
+    toff[t * SCAN_NEW + e] = 0;
+  }
+  tq[t] = frozen ? 0.0 : sc * (-achain / diag);
+  int nn = 0;
+  for (int e = 0; e < UN; ++e) {
+    const uint32_t code = (uint32_t)(wtab[t * WORDS + (e >> 3)] >> (8 * (e & 7))) & 0xFFu;
+    if (code == 0xFFu || frozen) continue;
+    const ScanEntry en = tab[code];
+    const bool new_side = en.off != chain && (backward ? en.off > 0 : en.off < 0);
+    if (new_side && nn < SCAN_NEW) {
+      tw[t * SCAN_NEW + nn] = sc * (en.v / diag);
+      toff[t * SCAN_NEW + nn] = en.off;
+      ++nn;
+    }
+  }
+}
+template <int WORDS, int UN>
+__global__ __launch_bounds__(256) void gs_scan_prep_typed_kernel(
+    int n, const uint8_t* __restrict__ rtype, const uint64_t* __restrict__ rwords,
+    const int32_t* __restrict__ doff, const double* __restrict__ dval, int ntab,
+    const double* __restrict__ b, const double* __restrict__ u, int backward, int mode, double omega,
+    double* __restrict__ P) {
+  __shared__ ScanEntry tab[256];
+  __shared__ uint64_t wtab[256 * WORDS];
+  scan_stage_tables(tab, wtab, WORDS, rtype, rwords, doff, dval, ntab);
+  __syncthreads();
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  uint64_t cw[2];
+  scan_row_words<WORDS>(cw, k, rwords, rtype, wtab);  // (codes unused: the matrix is row-typed)
+  double uv[UN], vv[UN];
+  bool side[UN];
+  double diag = 0.0;
+#pragma unroll
+  for (int e = 0; e < UN; ++e) {
+    const uint32_t code = (uint32_t)(cw[e >> 3] >> (8 * (e & 7))) & 0xFFu;
+    const ScanEntry en = tab[code == 0xFFu ? 0 : code];
+    side[e] = code != 0xFFu && (backward ? en.off < 0 : en.off > 0);
+    diag = (code != 0xFFu && en.off == 0) ? en.v : diag;
+    vv[e] = en.v;
+    uv[e] = u[side[e] ? k + en.off : k];
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int e = 0; e < UN; ++e) s = side[e] ? s + vv[e] * uv[e] : s;
+  const double uk = u[k];
+  double p;
+  if (mode == 0 && diag == 0.0) {
+    p = uk;
+  } else {
+    const double g = (b[k] - s) / diag;
+    p = mode == 2 ? uk + omega * (g - uk) : g;
+  }
+  P[k] = p;
+}
+template <int WORDS, int UN>
+__global__ __launch_bounds__(1024) void gs_scan_typed_kernel(
+    int n, const uint8_t* __restrict__ rtype, const uint64_t* __restrict__ rwords,
+    const int32_t* __restrict__ doff, const double* __restrict__ dval, int ntab, double* u,
+    const double* __restrict__ P, int backward, int mode, double omega, int C, int ringmask) {
+  extern __shared__ double ring[];           // new values of the last rows, by row & ringmask
+  __shared__ ScanEntry tab[256];
+  __shared__ uint64_t wtab[256 * WORDS];
+  __shared__ double tq[256];
+  __shared__ double tw[256 * SCAN_NEW];
+  __shared__ int32_t toff[256 * SCAN_NEW];
+  __shared__ double totQ[16], totC[16], carry_in[16];
+  __shared__ double last_u;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  scan_stage_tables(tab, wtab, WORDS, rtype, rwords, doff, dval, ntab);
+  for (int i = t; i <= ringmask; i += 1024) ring[i] = 0.0;
+  if (t == 0) last_u = 0.0;
+  __syncthreads();
+  scan_build_types<WORDS, UN>(tq, tw, toff, tab, wtab, backward, mode, omega);
+  __syncthreads();
+  const int nchunks = (n + C - 1) / C;
+  struct Row {
+    double p;
+    uint32_t ty;
+    int k;
+    bool live;
+  };
+  auto fetch = [&](int chunk, Row& r) {
+    const int idx = chunk * C + t;
+    r.live = chunk < nchunks && t < C && idx < n;
+    r.k = backward ? n - 1 - idx : idx;
+    r.ty = 255;
+    r.p = 0.0;
+    if (!r.live) return;
+    r.ty = rtype[r.k];
+    r.p = P[r.k];
+  };
+  const bool active = wave * 64 < C;
+  const int nwaves = (C + 63) >> 6;
+  Row cur, nx1, nx2;
+  cur.live = nx1.live = nx2.live = false;
+  if (active) {
+    fetch(0, cur);
+    fetch(1, nx1);
+  }
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    double Q = 1.0, Cc = 0.0;
+    if (active) {
+      fetch(chunk + 2, nx2);  // in flight during two scans
+      double q = 0.0, c = 0.0;
+      if (cur.live) {
+        const int tb = (int)cur.ty * SCAN_NEW;
+        double rv[SCAN_NEW], wv[SCAN_NEW];
+#pragma unroll
+        for (int e = 0; e < SCAN_NEW; ++e) {
+          wv[e] = tw[tb + e];
+          rv[e] = ring[(cur.k + toff[tb + e]) & ringmask];
+        }
+        c = cur.p;
+#pragma unroll
+        for (int e = 0; e < SCAN_NEW; ++e) c -= wv[e] * rv[e];   // unused slots: weight 0
+        q = tq[cur.ty];
+      }
+      Q = q;
+      Cc = c;
+      affine_scan_wave(Q, Cc);
+      if (lane == 63) {
+        totQ[wave] = Q;
+        totC[wave] = Cc;
+      }
+    }
+    lds_barrier();
+    if (wave == 0) {
+      double tq = lane < nwaves ? totQ[lane & 15] : 1.0, tc = lane < nwaves ? totC[lane & 15] : 0.0;
+      affine_scan_wave(tq, tc);
+      const double after = tc + tq * last_u;
+      if (lane < 15) carry_in[lane + 1] = after;
+      if (lane == 0) carry_in[0] = last_u;
+    }
+    lds_barrier();
+    if (active) {
+      const double unew = Cc + Q * carry_in[wave];
+      if (cur.live) {
+        ring[cur.k & ringmask] = unew;
+        u[cur.k] = unew;
+      }
+      const int last_t = (chunk * C + C <= n ? C : n - chunk * C) - 1;
+      if (t == last_t) last_u = unew;
+    }
+    lds_barrier();
+    cur = nx1;
+    nx1 = nx2;
+  }
+}
+
 template <int WORDS, int UN>
 static hipError_t launch_gs_scan_wu(int64_t n, const DictRef& D, const double* b, double* u,
                                     double* s_old, int backward, int mode, double omega, int C,
@@ -2137,6 +2320,21 @@ static hipError_t launch_gs_scan_wu(int64_t n, const DictRef& D, const double* b
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gs_scan_kernel<WORDS, UN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     attr_set = true;
+  }
+  if (D.rtype && g_scan_typed && D.scan_new <= SCAN_NEW) {
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gs_scan_typed_kernel<WORDS, UN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      attr2 = true;
+    }
+    hipLaunchKernelGGL((gs_scan_prep_typed_kernel<WORDS, UN>), dim3((unsigned)((n + 255) / 256)), dim3(256),
+                       0, st, (int)n, D.rtype, D.rwords, D.doff, D.dval, D.ntab, b, u, backward, mode, omega,
+                       s_old);
+    hipLaunchKernelGGL((gs_scan_typed_kernel<WORDS, UN>), dim3(1), dim3(1024), (size_t)ring * 8, st, (int)n,
+                       D.rtype, D.rwords, D.doff, D.dval, D.ntab, u, s_old, backward, mode, omega, C,
+                       ring - 1);
+    return hipGetLastError();
   }
   hipLaunchKernelGGL((gs_scan_prep_kernel<WORDS, UN>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                      (int)n, D.codes, D.rtype, D.rwords, D.doff, D.dval, D.ntab, u, backward, s_old);

@@ -39,6 +39,7 @@ struct DictRef {  // device pointers of one dictionary-coded matrix
   const uint64_t* rwords = nullptr;  // 256 * words, entry 255 = all 0xFF
   const int32_t* doff = nullptr;     // pair table: column offset from the diagonal column
   const double* dval = nullptr;      //             value
+  int scan_new = 99;                 // most entries of a row on one side beyond +-1 (K-GS-scan)
 };
 void set_xcd_mapping(int on);  // contiguous run of tiles per XCD (default on)
 void set_dict_rows_per_lane(int r);  // 1 or 2 (default), tuning / test switch
@@ -186,6 +187,7 @@ hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, 
 // Line-scan form of the lexicographic sweeps on a dictionary-coded matrix (K-GS-scan):
 // chunks of C rows, the in-chunk chain u_k = c_k + q_k u_{k-1} solved by an affine scan.
 // mode 0 SpGS update, 1 reference "Jacobi" (forward GS), 2 SOR.  ring: power of two.
+void set_scan_typed(int on);  // K-GS-scan: per-type fast path on row-typed matrices (default on)
 // s_old: scratch of n doubles (the sums over rows the sweep has not reached, formed by a
 // parallel pre-pass).
 hipError_t launch_gs_scan(int64_t n, const DictRef& D, const double* b, double* u, double* s_old,

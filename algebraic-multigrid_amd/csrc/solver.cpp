@@ -193,6 +193,7 @@ struct DevMat {
   // K-GS-scan: nearest dependency of a lexicographic sweep other than the chained neighbour
   // (min |offset| over the pairs with |offset| >= 2) and the farthest one; 0 = not usable
   int64_t scan_gap = 0, scan_far = 0;
+  int scan_new = 99;  // most entries of a row type beyond the chained neighbour on one side
   // K-Patch (temporal blocking): per (row type, slot) table, pitch of the band
   bool patch = false;
   int64_t patch_m = 0;
@@ -218,6 +219,7 @@ struct DevMat {
     D.rwords = dict_typed ? drwords.as<uint64_t>() : nullptr;
     D.doff = doff.as<int32_t>();
     D.dval = dval.as<double>();
+    D.scan_new = scan_new;
     return D;
   }
 };
@@ -334,6 +336,21 @@ hipError_t finish_dict(const DictMat& T, int64_t n, int64_t diag_shift, DevMat* 
     }
     D->scan_gap = gap == INT64_MAX ? (int64_t)1 << 20 : gap;
     D->scan_far = far;
+    D->scan_new = 99;
+    if (!T.rwords.empty()) {  // per row type: entries below -1 / above +1
+      int mx = 0;
+      for (int t = 0; t < 255; ++t) {
+        int lo = 0, hi = 0;
+        for (int e = 0; e < 8 * T.words; ++e) {
+          const int code = (int)((T.rwords[(size_t)t * T.words + e / 8] >> (8 * (e % 8))) & 0xFF);
+          if (code == 0xFF || code >= (int)T.doff.size()) continue;
+          if (T.doff[code] < -1) ++lo;
+          if (T.doff[code] > 1) ++hi;
+        }
+        mx = std::max(mx, std::max(lo, hi));
+      }
+      D->scan_new = mx;
+    }
   }
   D->patch = false;
   if (D->dict_typed && diag_shift == 0) {
