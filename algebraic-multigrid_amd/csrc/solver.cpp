@@ -525,6 +525,9 @@ struct CoarseOnDev {
 };
 // level-0 rows from which the lexicographic smoothers take the line-scan form by default
 constexpr int64_t GS_SCAN_MIN_ROWS = 65536;
+// ... and the shortest chunk worth it: a chunk costs ~1 us whatever its length, a serial row of
+// the exact kernel ~0.33 us, so below 4 rows per chunk the exact kernel is as fast
+constexpr int64_t GS_SCAN_MIN_GAP = 4;
 // serial substitution costs ~44 ns per row and pass; from this size on the partitioned
 // solve is the default (opt.exact_coarse_solve keeps the bit-exact one)
 constexpr int64_t COARSE_SPIKE_MIN_ROWS = 4096;
@@ -1161,7 +1164,7 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     if (s->opt.smoother <= AMG_HIP_SM_SOR && !s->opt.exact_gs && s->lv[0].n > GS_SCAN_MIN_ROWS &&
         L.symmetric) {
       const DevMat& A = L.A_rows;
-      if (A.dict && A.dict_shift == 0 && A.scan_gap >= 32) {
+      if (A.dict && A.dict_shift == 0 && A.scan_gap >= GS_SCAN_MIN_GAP) {
         int ring = 128;
         const int C = (int)std::min<int64_t>(A.scan_gap, 1024);
         while (ring < A.scan_far + C + 1 && ring <= 16384) ring *= 2;
@@ -1580,7 +1583,7 @@ amg_hip_status build_poisson_device(int dim, int64_t n, int32_t n_levels, const 
       int ring = 128;
       const int C = (int)std::min<int64_t>(A.scan_gap, 1024);
       while (ring < A.scan_far + C + 1 && ring <= 16384) ring *= 2;
-      if (A.scan_gap < 32 || ring > 16384) return AMG_HIP_OK;
+      if (A.scan_gap < GS_SCAN_MIN_GAP || ring > 16384) return AMG_HIP_OK;
       L.scan_C = C;
       L.scan_ring = ring;
     }

@@ -179,3 +179,22 @@ def test_device_pointer_csr_api(amg, oracle):
     # misaligned matrix arrays are refused, not mis-read
     assert lib.amg_hip_dev_spmv(n, A.nnz, mb, mr, rp.data_ptr(), ci.data_ptr() + 4, va.data_ptr(),
                                 t(u).data_ptr(), out.data_ptr(), None) == amg.EINVAL
+
+
+def test_non_finite_input_ends_the_solve_loop_like_the_reference(amg, oracle, capsys):
+    """NaN in b: the reference's loop `while (iter < n_iters && error > tolerance)`
+    (multigrid.hpp:317) leaves at the first rss check because NaN > tol is false, and prints
+    "did not converge".  Same here: no hang, rss is NaN, converged is False.  (Which ENTRIES turn
+    NaN can differ from the reference: the device kernels skip exact-zero entries and unused
+    slots, x + 0*NaN is only defined for finite vectors -- outside the parity contract.)"""
+    n, L = 24, 3
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    b = b.copy()
+    b[100] = np.nan
+    for kw in (dict(), dict(smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)):
+        mg = amg.Multigrid(*csc(A), b, L, compute_error_every_n_iters=5, n_iters=100, **kw)
+        u, iters, converged, last = mg.solve()
+        assert iters == 5 and not converged and np.isnan(last)
+        assert np.isnan(mg.rss()) and np.isnan(u).any()
+        mg.close()
+    assert "AMG did not converge after 5 iterations." in capsys.readouterr().out

@@ -500,3 +500,29 @@ def test_device_setup_time_4096(amg):
     assert mg.rss() < r3
     assert dt < 1.0
     mg.close()
+
+
+def test_scan_kernel_variants_agree_with_oracle(amg, oracle):
+    """K-GS-scan has a per-row-type fast path (row-typed dictionaries) and a general one (code
+    words per row): both within 1e-10 of the oracle and within 1e-12 of each other; a 3-D grid
+    (two non-chain dependencies, plane-sized ring) goes through the same kernels."""
+    out = {}
+    for typed in (True, False):
+        amg.set_row_types(typed)
+        try:
+            for n, L, dim in ((280, 4, 2), (44, 3, 3)):
+                A, b = oracle.laplacian(n, dim=dim), oracle.rhs(n, dim=dim)
+                ref = oracle.Multigrid(A, b, L)
+                mg = amg.Multigrid(*csc(A), b, L, exact_coarse_solve=True)
+                for _ in range(2):
+                    ref.vcycle()
+                    mg.vcycle()
+                u, ur = mg.get_soln(0), ref.get_vec(0, "u")
+                assert np.linalg.norm(u - ur) <= 1e-10 * np.linalg.norm(ur), (typed, n, dim)
+                out[(typed, n, dim)] = u
+                mg.close()
+        finally:
+            amg.set_row_types(True)
+    for key in [k for k in out if k[0]]:
+        a, c = out[key], out[(False,) + key[1:]]
+        assert np.linalg.norm(a - c) <= 1e-12 * np.linalg.norm(a)
