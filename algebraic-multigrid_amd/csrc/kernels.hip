@@ -1301,7 +1301,7 @@ hipError_t launch_patch_down(bool first, int64_t n, int64_t m, const PatchRef& P
     return hipErrorInvalidValue;
   int pxc = 0;
   const unsigned grid = patch_grid(n, m, &pxc);
-  const int xm = (g_xcd_map && !P.nt) ? 1 : 0;
+  const int xm = g_xcd_map ? 1 : 0;  // halo lines of neighbouring patches meet in one L2
   return patch_dispatch(P.un, P.nt != 0, [&](auto U, auto NTF) {
     if (first)
       hipLaunchKernelGGL((patch_down_kernel<decltype(U)::value, true, decltype(NTF)::value>), dim3(grid),
@@ -1321,7 +1321,7 @@ hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double
     return hipErrorInvalidValue;
   int pxc = 0;
   const unsigned grid = patch_grid(n, m, &pxc);
-  const int xm = (g_xcd_map && !P.nt) ? 1 : 0;
+  const int xm = g_xcd_map ? 1 : 0;  // halo lines of neighbouring patches meet in one L2
   return patch_dispatch(P.un, P.nt != 0, [&](auto U, auto NTF) {
     hipLaunchKernelGGL((patch_up_kernel<decltype(U)::value, decltype(NTF)::value>), dim3(grid),
                        dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, uH,
