@@ -1055,6 +1055,8 @@ void compute_bytes(amg_hip_solver* s) {
 }
 
 // ---- setup --------------------------------------------------------------------
+hipError_t device_dict_encode(const DevCsr& A, bool prune, int maxlen, DevMat* D, bool* ok);
+
 amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* rowind,
                             const double* val, const double* b, int32_t n_levels,
                             const int32_t* const* Pc, const int32_t* const* Pr,
@@ -1140,10 +1142,34 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     L.nnz_struct = L.A_csc.nnz();
     if (dev) {
     const bool prune = !s->opt.keep_structural_zeros;
-    HIP_TRY(upload_mat_pruned(A_r, s->opt.layout, prune, &L.A_rows));
-    if (!L.symmetric && s->opt.smoother >= AMG_HIP_SM_JACOBI)
-      HIP_TRY(upload_mat_pruned(L.A_csc, s->opt.layout, prune, &L.A_cols_own));
-    if (s->opt.smoother == AMG_HIP_SM_JACOBI) {  // diagonal of the column-as-row walk
+    // Symmetric levels headed for the dictionary layout are encoded ON THE DEVICE from CSR(A_l)
+    // (K-Setup: the encoder kernels check every row against a table proposed from a sample of
+    // rows); the arrays are there anyway for the Galerkin chain.  Everything else takes the
+    // host encoder.
+    bool encoded = false;
+    if (L.symmetric && (s->opt.layout == AMG_HIP_LAYOUT_AUTO || s->opt.layout == AMG_HIP_LAYOUT_DICT) &&
+        L.n >= (1 << 16) && A_r.nnz() < ((int64_t)1 << 31) - 1) {
+      if (!galerkin_on_dev) {
+        HIP_TRY(upload_csr(A_r, &galerkin_A));
+        galerkin_on_dev = true;
+      }
+      DevMem stats;
+      HIP_TRY(stats.alloc(sizeof(int32_t) * 2));
+      HIP_TRY(hipMemset(stats.p, 0, sizeof(int32_t) * 2));
+      HIP_TRY(L.diag.alloc(sizeof(double) * L.n));
+      HIP_TRY(launch_csr_inspect(L.n, galerkin_A.rowptr(), galerkin_A.col(), galerkin_A.v(), prune,
+                                 stats.as<int32_t>(), L.diag.as<double>(), nullptr));
+      int32_t st2[2];
+      HIP_TRY(hipMemcpy(st2, stats.p, sizeof(st2), hipMemcpyDeviceToHost));
+      if (st2[1] == 0) HIP_TRY(device_dict_encode(galerkin_A, prune, st2[0], &L.A_rows, &encoded));
+      if (!encoded || s->opt.smoother != AMG_HIP_SM_JACOBI) L.diag.release();
+    }
+    if (!encoded) {
+      HIP_TRY(upload_mat_pruned(A_r, s->opt.layout, prune, &L.A_rows));
+      if (!L.symmetric && s->opt.smoother >= AMG_HIP_SM_JACOBI)
+        HIP_TRY(upload_mat_pruned(L.A_csc, s->opt.layout, prune, &L.A_cols_own));
+    }
+    if (s->opt.smoother == AMG_HIP_SM_JACOBI && !L.diag.p) {  // diagonal of the column-as-row walk
       std::vector<double> dg(L.n, 0.0);
       for (int64_t c = 0; c < L.n; ++c)
         for (int32_t p = L.A_csc.ptr[c]; p < L.A_csc.ptr[c + 1]; ++p)
