@@ -2890,6 +2890,75 @@ __global__ __launch_bounds__(256) void galerkin_rap_kernel(
   }
   if (!FILL) cnt[j] = n_out;
 }
+// General C = A B on CSR arrays (custom interpolators: A P and R (A P), multigrid.hpp:219-223)
+// in Eigen's conservative-product order: row i of C is the K-way merge of the rows B[k, :] for
+// the K entries k of A's row i; an output entry exists as soon as one product touches it, its
+// first product is assigned and the later ones are added in ascending k (= the order of A's
+// row) -- the same bits as host_setup.cpp: spgemm_csr.  Thread per output row, K <= 32 cursors
+// (rows of A longer than that raise *overflow and the host product is used instead).
+constexpr int SPGEMM_K = 32;
+template <bool FILL>
+__global__ __launch_bounds__(128) void spgemm_kway_kernel(
+    int64_t n_rows, const int32_t* __restrict__ arp, const int32_t* __restrict__ acol,
+    const double* __restrict__ aval, const int32_t* __restrict__ brp, const int32_t* __restrict__ bcol,
+    const double* __restrict__ bval, int32_t* __restrict__ cnt, const int32_t* __restrict__ orp,
+    int32_t* __restrict__ ocol, double* __restrict__ oval, int32_t* __restrict__ overflow) {
+  const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
+  if (i >= n_rows) return;
+  const int32_t a0 = arp[i], K = arp[i + 1] - a0;
+  if (K > SPGEMM_K) {
+    if (!FILL) cnt[i] = 0;
+    atomicOr(overflow, 1);
+    return;
+  }
+  int32_t q[SPGEMM_K], e[SPGEMM_K];
+  for (int t = 0; t < K; ++t) {
+    const int32_t k = acol[a0 + t];
+    q[t] = brp[k];
+    e[t] = brp[k + 1];
+  }
+  int32_t n_out = 0;
+  const int64_t base = FILL ? orp[i] : 0;
+  for (;;) {
+    int32_t c = INT32_MAX;
+    for (int t = 0; t < K; ++t)
+      if (q[t] < e[t]) {
+        const int32_t cc = bcol[q[t]];
+        c = cc < c ? cc : c;
+      }
+    if (c == INT32_MAX) break;
+    double v = 0.0;
+    bool started = false;
+    for (int t = 0; t < K; ++t)
+      if (q[t] < e[t] && bcol[q[t]] == c) {
+        if (FILL) {
+          const double p = aval[a0 + t] * bval[q[t]];
+          v = started ? v + p : p;
+          started = true;
+        }
+        ++q[t];
+      }
+    if (FILL) {
+      ocol[base + n_out] = c;
+      oval[base + n_out] = v;
+    }
+    ++n_out;
+  }
+  if (!FILL) cnt[i] = n_out;
+}
+hipError_t launch_spgemm(bool fill, int64_t n_rows, const int32_t* arp, const int32_t* acol,
+                         const double* aval, const int32_t* brp, const int32_t* bcol, const double* bval,
+                         int32_t* cnt, const int32_t* orp, int32_t* ocol, double* oval,
+                         int32_t* overflow, hipStream_t st) {
+  const unsigned grid = (unsigned)((n_rows + 127) / 128);
+  if (fill)
+    hipLaunchKernelGGL(spgemm_kway_kernel<true>, dim3(grid), dim3(128), 0, st, n_rows, arp, acol, aval, brp,
+                       bcol, bval, cnt, orp, ocol, oval, overflow);
+  else
+    hipLaunchKernelGGL(spgemm_kway_kernel<false>, dim3(grid), dim3(128), 0, st, n_rows, arp, acol, aval,
+                       brp, bcol, bval, cnt, orp, ocol, oval, overflow);
+  return hipGetLastError();
+}
 // exclusive scan of n int32 counts into n + 1 offsets (three small kernels)
 __global__ __launch_bounds__(256) void scan_block_sums_kernel(int64_t n, const int32_t* __restrict__ in,
                                                               int64_t* __restrict__ bsum) {

@@ -224,6 +224,12 @@ hipError_t launch_spike_solve(const SpikeArgs& a, hipStream_t st);
 // counts) around launch_exclusive_scan.  Same entry order and bits as spgemm_csr.
 hipError_t launch_exclusive_scan(int64_t n, const int32_t* counts, int32_t* offsets, int64_t* bsum,
                                  int64_t* total, hipStream_t st);
+// general CSR x CSR product, Eigen's conservative order (count pass: cnt; fill pass: orp); rows
+// of A with more than 32 entries set *overflow
+hipError_t launch_spgemm(bool fill, int64_t n_rows, const int32_t* arp, const int32_t* acol,
+                         const double* aval, const int32_t* brp, const int32_t* bcol, const double* bval,
+                         int32_t* cnt, const int32_t* orp, int32_t* ocol, double* oval,
+                         int32_t* overflow, hipStream_t st);
 hipError_t launch_galerkin_ap(bool fill, int64_t n_h, int64_t n_H, const int32_t* arp,
                               const int32_t* acol, const double* aval, int32_t* cnt,
                               const int32_t* orp, int32_t* ocol, double* oval, hipStream_t st);

@@ -175,6 +175,66 @@ hipError_t device_galerkin(const DevCsr& A, int64_t n_H, DevCsr* AH, Sparse* hos
   return hipSuccess;
 }
 
+// C = A B on the device (general CSR operands: custom interpolators), count -> scan -> fill.
+// *ok = false: a row of A is longer than the kernel's merge width, or an index overflow:
+// the caller takes the host product.
+hipError_t device_spgemm(const DevCsr& A, const DevCsr& B, DevCsr* C, bool* ok) {
+  *ok = false;
+  const int64_t n = A.n_rows;
+  hipError_t e;
+  DevMem cnt, bsum, total, ovf;
+  if ((e = cnt.alloc(sizeof(int32_t) * (n + 1))) != hipSuccess) return e;
+  if ((e = bsum.alloc(sizeof(int64_t) * ((n + 1023) / 1024 + 1))) != hipSuccess) return e;
+  if ((e = total.alloc(sizeof(int64_t))) != hipSuccess) return e;
+  if ((e = ovf.alloc(sizeof(int32_t))) != hipSuccess) return e;
+  if ((e = hipMemset(ovf.p, 0, sizeof(int32_t))) != hipSuccess) return e;
+  if ((e = launch_spgemm(false, n, A.rowptr(), A.col(), A.v(), B.rowptr(), B.col(), B.v(),
+                         cnt.as<int32_t>(), nullptr, nullptr, nullptr, ovf.as<int32_t>(), nullptr)) != hipSuccess)
+    return e;
+  int32_t over = 0;
+  if ((e = hipMemcpy(&over, ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+  if (over) return hipSuccess;
+  if ((e = C->ptr.alloc(sizeof(int32_t) * (n + 1))) != hipSuccess) return e;
+  if ((e = launch_exclusive_scan(n, cnt.as<int32_t>(), C->ptr.as<int32_t>(), bsum.as<int64_t>(),
+                                 total.as<int64_t>(), nullptr)) != hipSuccess)
+    return e;
+  int64_t nnz = 0;
+  if ((e = hipMemcpy(&nnz, total.p, sizeof(int64_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+  if (nnz >= ((int64_t)1 << 31) - 1) return hipSuccess;
+  if ((e = C->idx.alloc(sizeof(int32_t) * std::max<int64_t>(nnz, 1))) != hipSuccess) return e;
+  if ((e = C->val.alloc(sizeof(double) * std::max<int64_t>(nnz, 1))) != hipSuccess) return e;
+  if ((e = launch_spgemm(true, n, A.rowptr(), A.col(), A.v(), B.rowptr(), B.col(), B.v(), nullptr,
+                         C->ptr.as<int32_t>(), C->idx.as<int32_t>(), C->val.as<double>(),
+                         ovf.as<int32_t>(), nullptr)) != hipSuccess)
+    return e;
+  C->n_rows = n;
+  C->n_cols = B.n_cols;
+  C->nnz = nnz;
+  *ok = true;
+  return hipSuccess;
+}
+// A_H = R (A P) for arbitrary transfer operators (CSR(R), CSR(P) on the device); host copy of
+// CSR(A_H) as for device_galerkin
+hipError_t device_galerkin_generic(const DevCsr& A, const DevCsr& P, const DevCsr& R, DevCsr* AH,
+                                   Sparse* host, bool* ok) {
+  DevCsr AP;
+  hipError_t e = device_spgemm(A, P, &AP, ok);
+  if (e != hipSuccess || !*ok) return e;
+  e = device_spgemm(R, AP, AH, ok);
+  if (e != hipSuccess || !*ok) return e;
+  const int64_t n_H = AH->n_rows, nnz = AH->nnz;
+  host->n_outer = host->n_inner = n_H;
+  host->ptr.resize(n_H + 1);
+  host->idx.resize(nnz);
+  host->val.resize(nnz);
+  if ((e = hipMemcpy(host->ptr.data(), AH->ptr.p, sizeof(int32_t) * (n_H + 1), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+  if (nnz > 0) {
+    if ((e = hipMemcpy(host->idx.data(), AH->idx.p, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+    if ((e = hipMemcpy(host->val.data(), AH->val.p, sizeof(double) * nnz, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 // A level matrix on the device in one of the two layouts the kernels take.
 struct DevMat {
   bool sell = false;
@@ -1279,13 +1339,26 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     // Galerkin (multigrid.hpp:219-223), row-major, Eigen's summation order: on the device
     // for the linear interpolation pair (K-Galerkin), else on the host (same bits)
     Sparse AH_r;
+    bool done = false;
     if (dev_galerkin) {
       if (!galerkin_on_dev) HIP_TRY(upload_csr(A_r, &galerkin_A));
       DevCsr next;
       HIP_TRY(device_galerkin(galerkin_A, n_H, &next, &AH_r));
       galerkin_A = std::move(next);
       galerkin_on_dev = true;
-    } else {
+      done = true;
+    } else if (dev && dev_rows && !s->opt.host_galerkin) {
+      // custom interpolator: general K-way-merge product on the device (CSR(P), CSR(R) were
+      // uploaded for the transfer kernels anyway)
+      if (!galerkin_on_dev) HIP_TRY(upload_csr(A_r, &galerkin_A));
+      DevCsr next;
+      HIP_TRY(device_galerkin_generic(galerkin_A, L.P_rows, L.R_rows, &next, &AH_r, &done));
+      if (done) {
+        galerkin_A = std::move(next);
+        galerkin_on_dev = true;
+      }
+    }
+    if (!done) {
       AH_r = galerkin_csr(R_r, A_r, P_r, nt);
       galerkin_on_dev = false;
     }

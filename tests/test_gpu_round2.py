@@ -526,3 +526,34 @@ def test_scan_kernel_variants_agree_with_oracle(amg, oracle):
     for key in [k for k in out if k[0]]:
         a, c = out[key], out[(False,) + key[1:]]
         assert np.linalg.norm(a - c) <= 1e-12 * np.linalg.norm(a)
+
+
+def test_custom_interpolator_galerkin_on_device_matches_host(amg, oracle):
+    """A user InterpolatorBase (interpolator.hpp:43-44) with operators that are NOT the built-in
+    linear pair: the Galerkin chain R (A P) (multigrid.hpp:219-223) runs as a general K-way
+    merge product on the device; pattern (structural zeros included) and values must be the
+    host product's, bit for bit, on every level, and so must the V-cycles."""
+    n, L = 150, 5
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    ref = oracle.Multigrid(A, b, L)
+    rng = np.random.default_rng(8)
+    tr = []
+    for l in range(L - 1):
+        P, R = ref.transfer(l, "P"), ref.transfer(l, "R")
+        # perturb the weights (keeps the sparsity pattern, breaks R = P^T and the 0.5 / 1 / 0.5 values)
+        pv = P.val * (1.0 + 0.1 * rng.random(P.val.size))
+        rv = R.val * (1.0 + 0.1 * rng.random(R.val.size))
+        tr.append(((P.colptr, P.rowind, pv), (R.colptr, R.rowind, rv)))
+    kw = dict(smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.5, exact_coarse_solve=True)
+    dev = amg.Multigrid(*csc(A), b, L, transfers=tr, **kw)
+    host = amg.Multigrid(*csc(A), b, L, transfers=tr, host_galerkin=True, **kw)
+    for l in range(L):
+        a, c = dev.get_coefficient_matrix(l), host.get_coefficient_matrix(l)
+        assert all(np.array_equal(x, y) for x, y in zip(a, c)), l
+    dev.vcycle(3)
+    host.vcycle(3)
+    for l in range(L - 1):
+        assert np.array_equal(dev.get_soln(l), host.get_soln(l)), l
+    assert np.isfinite(dev.rss())
+    dev.close()
+    host.close()
