@@ -105,10 +105,6 @@ hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double
 // uh_out = uh_in + P uH for the linear interpolation pair (16-byte aligned vectors)
 hipError_t launch_linear_prolong_to(int64_t n_h, int64_t n_H, const double* uH,
                                     const double* uh_in, double* uh_out, hipStream_t st);
-hipError_t launch_dict(int mode, int64_t n, int words, int wmax, int nt, const uint64_t* codes,
-                       const int32_t* doff, const double* dval, int ntab, const double* x,
-                       const double* f, double* out, double omega, int64_t diag_shift,
-                       hipStream_t st);
 hipError_t launch_sell_jacobi_prolong(int64_t n, int idx16, const int64_t* soff,
                                       const void* scol, const double* sval, const double* u,
                                       const double* uH, int64_t nH, const double* f, double* out,

@@ -678,22 +678,24 @@ struct Level {
   int64_t n = 0;
   int64_t nnz_struct = 0;  // structural entries (exact zeros of the Galerkin product included)
   // host copy, what get_coefficient_matrix returns.  Device-only setup (amg_hip_create_poisson)
-  // leaves it empty and keeps CSR(A) on the device instead; host_matrix() fills it on demand.
+  // leaves it empty and keeps CSR(A) on the device instead; ensure_host_matrix() fills it on demand.
   mutable Sparse A_csc;
   DevCsr A_dev;
-  const Sparse& host_matrix() const {
-    if (A_csc.ptr.empty() && A_dev.n_rows > 0) {  // symmetric: the CSR arrays are the CSC arrays
-      A_csc.n_outer = A_csc.n_inner = A_dev.n_rows;
-      A_csc.ptr.resize((size_t)A_dev.n_rows + 1);
-      A_csc.idx.resize((size_t)A_dev.nnz);
-      A_csc.val.resize((size_t)A_dev.nnz);
-      (void)hipMemcpy(A_csc.ptr.data(), A_dev.ptr.p, sizeof(int32_t) * A_csc.ptr.size(), hipMemcpyDeviceToHost);
-      if (A_dev.nnz > 0) {
-        (void)hipMemcpy(A_csc.idx.data(), A_dev.idx.p, sizeof(int32_t) * A_csc.idx.size(), hipMemcpyDeviceToHost);
-        (void)hipMemcpy(A_csc.val.data(), A_dev.val.p, sizeof(double) * A_csc.val.size(), hipMemcpyDeviceToHost);
-      }
+  hipError_t ensure_host_matrix() const {
+    if (!A_csc.ptr.empty() || A_dev.n_rows <= 0) return hipSuccess;
+    Sparse H;  // symmetric: the CSR arrays are the CSC arrays
+    H.n_outer = H.n_inner = A_dev.n_rows;
+    H.ptr.resize((size_t)A_dev.n_rows + 1);
+    H.idx.resize((size_t)A_dev.nnz);
+    H.val.resize((size_t)A_dev.nnz);
+    hipError_t e = hipMemcpy(H.ptr.data(), A_dev.ptr.p, sizeof(int32_t) * H.ptr.size(), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && A_dev.nnz > 0) {
+      e = hipMemcpy(H.idx.data(), A_dev.idx.p, sizeof(int32_t) * H.idx.size(), hipMemcpyDeviceToHost);
+      if (e == hipSuccess)
+        e = hipMemcpy(H.val.data(), A_dev.val.p, sizeof(double) * H.val.size(), hipMemcpyDeviceToHost);
     }
-    return A_csc;
+    if (e == hipSuccess) A_csc = std::move(H);
+    return e;
   }
   DevMat A_rows;           // rows of A: residual, rss
   DevMat A_cols_own;       // CSC arrays walked as rows (column-as-row smoothers,
@@ -1716,7 +1718,8 @@ amg_hip_status build_poisson_device(int dim, int64_t n, int32_t n_levels, const 
   lap("rhs");
   {
     const int want = o.fast_coarse_solve ? 1 : (o.exact_coarse_solve ? -1 : 0);
-    amg_hip_status r = upload_coarse(s->lv[n_levels - 1].host_matrix(), want, &s->coarse);
+    HIP_TRY(s->lv[n_levels - 1].ensure_host_matrix());
+    amg_hip_status r = upload_coarse(s->lv[n_levels - 1].A_csc, want, &s->coarse);
     if (r != AMG_HIP_OK) return r;
   }
   lap("coarse factor");
@@ -2093,7 +2096,9 @@ amg_hip_status amg_hip_get_level_matrix(const amg_hip_solver* s, int32_t level,
                                         int32_t* colptr, int32_t* rowind, double* val) {
   if (!s || level < 0 || level >= (int32_t)s->lv.size())
     return fail(AMG_HIP_EINVAL, "level out of range");
-  const Sparse& A = s->lv[level].host_matrix();
+  if (!s->opt.host_only) HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(s->lv[level].ensure_host_matrix());
+  const Sparse& A = s->lv[level].A_csc;
   if (colptr) std::memcpy(colptr, A.ptr.data(), sizeof(int32_t) * A.ptr.size());
   if (rowind) std::memcpy(rowind, A.idx.data(), sizeof(int32_t) * A.idx.size());
   if (val) std::memcpy(val, A.val.data(), sizeof(double) * A.val.size());
