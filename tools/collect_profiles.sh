@@ -16,5 +16,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $root/gpurun_ou
 cd $root
 cp gpurun_out/prof_$tag/d_kernel_stats.csv $out/${tag}_bench_kernel_stats.csv
 python3 tools/rocprof_summary.py gpurun_out/prof_$tag/d_kernel_trace.csv > $out/${tag}_bench_by_level.md
-PMC_OUT_DIR=$out python3 tools/pmc_traffic.py gpurun_out/pmc_f_$tag/d_counter_collection.csv gpurun_out/pmc_w_$tag/d_counter_collection.csv $tag > /dev/null
+note="default layout (dictionary-coded rows, K-Patch on levels 0-3)"
+case " $* " in *" --layout sell "*) note="--layout sell (CSR sliced into 64-row panels, 16-bit relative columns)";; esac
+PMC_OUT_DIR=$out python3 tools/pmc_traffic.py gpurun_out/pmc_f_$tag/d_counter_collection.csv gpurun_out/pmc_w_$tag/d_counter_collection.csv $tag "$note" > /dev/null
 grep -v "^$" $out/${tag}_pmc_traffic.md | head -30
