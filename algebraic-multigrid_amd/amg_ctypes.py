@@ -42,6 +42,19 @@ class Options(C.Structure):
                 ("stream", C.c_void_p)]
 
 
+SLAB_MAX_LEVELS = 8
+
+
+class SlabInfo(C.Structure):
+    """amg_hip_slab_info (include/amg_hip.h)"""
+    _fields_ = [("levels", C.c_int32), ("halo_lines", C.c_int32), ("lines", C.c_int64),
+                ("chunk_lines", C.c_int64), ("line_begin", C.c_int64), ("line_end", C.c_int64),
+                ("pitch0", C.c_int64), ("gather_pitch", C.c_int64), ("gather_rows", C.c_int64),
+                ("down_lo", C.c_int64 * SLAB_MAX_LEVELS), ("down_hi", C.c_int64 * SLAB_MAX_LEVELS),
+                ("up_lo", C.c_int64 * SLAB_MAX_LEVELS), ("up_hi", C.c_int64 * SLAB_MAX_LEVELS),
+                ("u0", C.c_void_p), ("f_gather", C.c_void_p)]
+
+
 class HaloDesc(C.Structure):
     _fields_ = [("dst_prev", C.c_void_p), ("src_prev", C.c_void_p), ("bytes_prev", C.c_int64),
                 ("dst_next", C.c_void_p), ("src_next", C.c_void_p), ("bytes_next", C.c_int64),
@@ -107,6 +120,9 @@ _SIGS = {
     "amg_hip_coarse_solve_kind": (C.c_int32, [C.c_void_p]),
     "amg_hip_fine_sweep_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _i32p, _f64p]),
     "amg_hip_set_patch_min_rows": (None, [C.c_int64]),
+    "amg_hip_slab_plan": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(SlabInfo)]),
+    "amg_hip_slab_setup": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(SlabInfo)]),
+    "amg_hip_slab_run": (C.c_int, [C.c_void_p, C.c_int32]),
     "amg_hip_level_layout": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "amg_hip_get_colors": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p]),
     "amg_hip_level_op": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
@@ -238,6 +254,13 @@ def dict_probe(rowptr, col, val, ncols, diag_shift=0):
         return None
     _chk(st)
     return a.value, b.value, c.value
+
+
+def slab_plan(lines, rank, world, levels):
+    """Host arithmetic of the slab sharding (no device): SlabInfo with the line ranges."""
+    info = SlabInfo()
+    _chk(lib().amg_hip_slab_plan(int(lines), int(rank), int(world), int(levels), C.byref(info)))
+    return info
 
 
 def set_patch_min_rows(rows):
@@ -491,6 +514,16 @@ class Multigrid:
         out = C.c_double(0)
         _chk(lib().amg_hip_rss(self._h, C.byref(out)))
         return out.value
+
+    def slab_setup(self, rank, world, max_levels=-1):
+        """Row-block sharding of the K-Patch levels over `world` ranks (amg_hip_slab_setup)."""
+        info = SlabInfo()
+        _chk(lib().amg_hip_slab_setup(self._h, int(rank), int(world), int(max_levels), C.byref(info)))
+        return info
+
+    def slab_run(self, part):
+        """1: down-legs of the slab levels, 2: replicated rest, 3: up-legs (amg_hip_slab_run)."""
+        _chk(lib().amg_hip_slab_run(self._h, int(part)))
 
     def apply_dev(self, v_dev, z_dev):
         """z = M^-1 v (one V-cycle from zero); device pointers."""

@@ -1204,13 +1204,13 @@ __global__ __launch_bounds__(PATCH_NT) void patch_down_kernel(
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
     int nent, int ntypes, const double* x, const double* __restrict__ f, double* u_out, double* r_out, int nH,
     double* __restrict__ fH, const double* __restrict__ diagH, double* __restrict__ uH1,
-    double omega, int xcd_map) {
+    double omega, int xcd_map, int py0) {
   __shared__ double buf[PATCH_BUF];
   __shared__ PatchJ tabJ[PATCH_MAXTAB];
   __shared__ PatchR tabR[PATCH_MAXTAB];
   const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
   const int py = tile / px_count, px = tile - py * px_count;
-  const int j0 = py * PATCH_TH, i0 = px * PATCH_TW;
+  const int j0 = (py + py0) * PATCH_TH, i0 = px * PATCH_TW;
   PatchCells pc;
   PatchU U;
   patch_load<false>(pc, n, m, j0, i0, x, f, rtype, ntypes, nullptr, 0, buf);
@@ -1252,13 +1252,13 @@ __global__ __launch_bounds__(PATCH_NT) void patch_up_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
     int nent, int ntypes, const double* x, const double* __restrict__ f, const double* __restrict__ uH, int nH,
-    double* u_out, double omega, int xcd_map) {
+    double* u_out, double omega, int xcd_map, int py0) {
   __shared__ double buf[PATCH_BUF];
   __shared__ PatchJ tabJ[PATCH_MAXTAB];
   __shared__ PatchR tabR[PATCH_MAXTAB];
   const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
   const int py = tile / px_count, px = tile - py * px_count;
-  const int j0 = py * PATCH_TH, i0 = px * PATCH_TW;
+  const int j0 = (py + py0) * PATCH_TH, i0 = px * PATCH_TW;
   PatchCells pc;
   PatchU U;
   patch_load<true>(pc, n, m, j0, i0, x, f, rtype, ntypes, uH, nH, buf);
@@ -1275,11 +1275,18 @@ int patch_un(int un) { return un <= 5 ? 5 : un <= 7 ? 7 : 9; }
 bool patch_geometry_ok(int64_t n, int64_t m) {
   return m >= 2 * PATCH_TW && (m % PATCH_TW) == 0 && n >= m && n < ((int64_t)1 << 31) - 4 * m - 64;
 }
-static unsigned patch_grid(int64_t n, int64_t m, int* px_count) {
+// tiles of the lines [line_lo, line_hi) (line_hi < 0: all); *py0 = first tile row
+static unsigned patch_grid(int64_t n, int64_t m, int64_t line_lo, int64_t line_hi, int* px_count,
+                           int* py0) {
   const int64_t lines = (n + m - 1) / m;
+  if (line_hi < 0 || line_hi > lines) line_hi = lines;
+  if (line_lo < 0) line_lo = 0;
+  if (line_lo > line_hi) line_lo = line_hi;
   *px_count = (int)(m / PATCH_TW);
-  return (unsigned)(((lines + PATCH_TH - 1) / PATCH_TH) * *px_count);
+  *py0 = (int)(line_lo / PATCH_TH);
+  return (unsigned)(((line_hi + PATCH_TH - 1) / PATCH_TH - *py0) * *px_count);
 }
+int patch_tile_lines() { return PATCH_TH; }
 template <class F>
 static hipError_t patch_dispatch(int un, bool nt, F&& go) {
   using std::integral_constant;
@@ -1295,37 +1302,40 @@ static hipError_t patch_dispatch(int un, bool nt, F&& go) {
 }
 hipError_t launch_patch_down(bool first, int64_t n, int64_t m, const PatchRef& P, const double* x,
                              const double* f, double* u_out, double* r_out, int64_t nH, double* fH,
-                             const double* diagH, double* uH1, double omega, hipStream_t st) {
+                             const double* diagH, double* uH1, double omega, hipStream_t st,
+                             int64_t line_lo, int64_t line_hi) {
   if (!patch_geometry_ok(n, m) || !P.rtype || !P.ptab || !P.utabd || !P.utabi || (P.ntypes + 1) * patch_un(P.un) > PATCH_MAXTAB ||
       P.nent != P.ntypes * patch_un(P.un) || !fH || !diagH || !uH1 || !u_out || u_out == x)
     return hipErrorInvalidValue;
-  int pxc = 0;
-  const unsigned grid = patch_grid(n, m, &pxc);
+  int pxc = 0, py0 = 0;
+  const unsigned grid = patch_grid(n, m, line_lo, line_hi, &pxc, &py0);
+  if (grid == 0) return hipSuccess;
   const int xm = g_xcd_map ? 1 : 0;  // halo lines of neighbouring patches meet in one L2
   return patch_dispatch(P.un, P.nt != 0, [&](auto U, auto NTF) {
     if (first)
       hipLaunchKernelGGL((patch_down_kernel<decltype(U)::value, true, decltype(NTF)::value>), dim3(grid),
                          dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, u_out,
-                         r_out, (int)nH, fH, diagH, uH1, omega, xm);
+                         r_out, (int)nH, fH, diagH, uH1, omega, xm, py0);
     else
       hipLaunchKernelGGL((patch_down_kernel<decltype(U)::value, false, decltype(NTF)::value>), dim3(grid),
                          dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, u_out,
-                         r_out, (int)nH, fH, diagH, uH1, omega, xm);
+                         r_out, (int)nH, fH, diagH, uH1, omega, xm, py0);
   });
 }
 hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double* x, const double* f,
                            const double* uH, int64_t nH, double* u_out, double omega,
-                           hipStream_t st) {
+                           hipStream_t st, int64_t line_lo, int64_t line_hi) {
   if (!patch_geometry_ok(n, m) || !P.rtype || !P.ptab || !P.utabd || !P.utabi || (P.ntypes + 1) * patch_un(P.un) > PATCH_MAXTAB ||
       P.nent != P.ntypes * patch_un(P.un) || !uH || !u_out || u_out == x)
     return hipErrorInvalidValue;
-  int pxc = 0;
-  const unsigned grid = patch_grid(n, m, &pxc);
+  int pxc = 0, py0 = 0;
+  const unsigned grid = patch_grid(n, m, line_lo, line_hi, &pxc, &py0);
+  if (grid == 0) return hipSuccess;
   const int xm = g_xcd_map ? 1 : 0;  // halo lines of neighbouring patches meet in one L2
   return patch_dispatch(P.un, P.nt != 0, [&](auto U, auto NTF) {
     hipLaunchKernelGGL((patch_up_kernel<decltype(U)::value, decltype(NTF)::value>), dim3(grid),
                        dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, uH,
-                       (int)nH, u_out, omega, xm);
+                       (int)nH, u_out, omega, xm, py0);
   });
 }
 int patch_lds_pitch() { return PATCH_EC; }

@@ -97,11 +97,15 @@ int patch_max_entries();
 // u_out = smoothed level vector (never x), r_out optional, f_H / uH1 as launch_dict_resid_restrict
 hipError_t launch_patch_down(bool first, int64_t n, int64_t m, const PatchRef& P, const double* x,
                              const double* f, double* u_out, double* r_out, int64_t nH, double* fH,
-                             const double* diagH, double* uH1, double omega, hipStream_t st);
+                             const double* diagH, double* uH1, double omega, hipStream_t st,
+                             int64_t line_lo = 0, int64_t line_hi = -1);
+// The patch launchers take a range of grid lines [line_lo, line_hi) (line_hi < 0: the whole
+// level): only the tiles that meet it run (row-block sharding, solver.cpp "slab").
+int patch_tile_lines();
 // u_out = two Jacobi sweeps of (x + P uH); u_out must not be x
 hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double* x, const double* f,
                            const double* uH, int64_t nH, double* u_out, double omega,
-                           hipStream_t st);
+                           hipStream_t st, int64_t line_lo = 0, int64_t line_hi = -1);
 // uh_out = uh_in + P uH for the linear interpolation pair (16-byte aligned vectors)
 hipError_t launch_linear_prolong_to(int64_t n_h, int64_t n_H, const double* uH,
                                     const double* uh_in, double* uh_out, hipStream_t st);

@@ -735,6 +735,30 @@ struct Level {
 
 }  // namespace
 
+// Row-block ("slab") sharding of the K-Patch levels: every rank holds the whole
+// hierarchy and full-size vectors, but runs the patch kernels of levels 0..levels-1 only over
+// its own grid lines plus a halo deep enough that NO exchange is needed inside those legs
+// (the halo lines are recomputed redundantly: each kernel stage makes one more line at either
+// end of the range stale, and the ranges below are what is left valid where it is needed).
+// The level below the slab levels is all-gathered and the rest of the cycle runs replicated.
+struct Slab {
+  int levels = 0;               // 0: not configured
+  int rank = 0, world = 1;
+  int64_t lines = 0, chunk = 0, line0 = 0, line1 = 0;   // grid lines; lines per rank; owned [line0, line1)
+  int halo = 0;                 // lines of level-0 u a neighbour supplies before each cycle
+  std::vector<int64_t> down_lo, down_hi, up_lo, up_hi;  // lines each leg runs over, per level
+  hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
+  hipGraphExec_t exec[3] = {nullptr, nullptr, nullptr};
+  void reset_graphs() {
+    for (int i = 0; i < 3; ++i) {
+      if (exec[i]) (void)hipGraphExecDestroy(exec[i]);
+      if (graph[i]) (void)hipGraphDestroy(graph[i]);
+      exec[i] = nullptr;
+      graph[i] = nullptr;
+    }
+  }
+};
+
 struct amg_hip_solver {
   amg_hip_options opt;
   int device = 0;
@@ -748,8 +772,10 @@ struct amg_hip_solver {
   hipGraphExec_t graph_exec = nullptr;
   bool graph_ready = false;
   double cycle_bytes = 0, fine_sweep_bytes = 0;
+  Slab slab;
 
   ~amg_hip_solver() {
+    slab.reset_graphs();
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
     if (stream && own_stream) (void)hipStreamDestroy(stream);
@@ -937,13 +963,28 @@ amg_hip_status enqueue_residual(amg_hip_solver* s, int l) {
   return AMG_HIP_OK;
 }
 
-// multigrid.hpp:263-305
-amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
+// multigrid.hpp:263-305.  part: the whole cycle, or one of the three pieces a slab-sharded
+// cycle is cut into at its two exchange points (struct Slab): the down-legs of the slab levels
+// over this rank's lines, the replicated rest below them (it begins by redoing the from-zero
+// sweep of its first level on the gathered right-hand side), the up-legs of the slab levels.
+enum { CYCLE_ALL = 0, CYCLE_SLAB_DOWN = 1, CYCLE_SLAB_TAIL = 2, CYCLE_SLAB_UP = 3 };
+amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
   const int nl = (int)s->lv.size();
   hipStream_t st = s->stream;
+  const Slab& sb = s->slab;
+  const int k = sb.levels;
+  const bool ranged = part == CYCLE_SLAB_DOWN || part == CYCLE_SLAB_UP;
   const bool zero_known = jacobi_fuses_zero(s);  // coarse pre-smoothing starts from u == 0
   bool first_sweep_done = false;  // by the fused residual+restrict kernel of level l-1
-  for (int l = 0; l < nl; ++l) {
+  if (part == CYCLE_SLAB_TAIL) {
+    Level& L = s->lv[k];
+    HIP_TRY(launch_jacobi_from_zero(L.n, L.diag.as<double>(), L.f.as<double>(), L.tmp.as<double>(),
+                                    s->opt.omega, st));
+    first_sweep_done = true;
+  }
+  const int down_from = part == CYCLE_SLAB_TAIL ? k : 0;
+  const int down_to = part == CYCLE_SLAB_DOWN ? k : (part == CYCLE_SLAB_UP ? 0 : nl);
+  for (int l = down_from; l < down_to; ++l) {
     // On the coarsest level the reference smooths and forms the residual, then overwrites
     // u with the direct solve of the level's rhs (multigrid.hpp:268-274, :287-288): unless
     // the residual is to be kept, neither has an observable effect.
@@ -958,7 +999,8 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
                                 first ? L.tmp.as<double>() : L.u.as<double>(),
                                 s->opt.keep_residual ? L.r.as<double>() : nullptr, C.n,
                                 C.f.as<double>(), C.diag.as<double>(), C.tmp.as<double>(),
-                                s->opt.omega, st));
+                                s->opt.omega, st, ranged ? sb.down_lo[l] : 0,
+                                ranged ? sb.down_hi[l] : -1));
       first_sweep_done = true;
       continue;
     }
@@ -1009,7 +1051,7 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
       }
     }
   }
-  {                                                                // :287-288
+  if (!ranged) {                                                   // :287-288
     Level& C = s->lv[nl - 1];
     HIP_TRY(launch_coarse(s->coarse, C.f.as<double>(), C.tmp.as<double>(), C.u.as<double>(), st));
   }
@@ -1019,7 +1061,9 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
   auto up_target = [&](int l) -> double* {
     return pair_up_ok(s, l) ? s->lv[l].tmp.as<double>() : s->lv[l].u.as<double>();
   };
-  for (int l = nl - 2; l >= 0; --l) {                              // :291
+  const int up_from = part == CYCLE_SLAB_UP ? k - 1 : (part == CYCLE_SLAB_DOWN ? -1 : nl - 2);
+  const int up_to = part == CYCLE_SLAB_TAIL ? k : 0;
+  for (int l = up_from; l >= up_to; --l) {                         // :291
     Level& L = s->lv[l];
     Level& C = s->lv[l + 1];
     if (patch_level_ok(s, l)) {  // :294-296 + :300 (both sweeps), one launch
@@ -1029,7 +1073,8 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s) {
       const double* uH = patch_level_ok(s, l + 1) ? C.tmp.as<double>() : C.u.as<double>();
       HIP_TRY(launch_patch_up(L.n, A.patch_m, A.patch_ref(),
                               top ? L.tmp.as<double>() : L.u.as<double>(), L.f.as<double>(), uH, C.n,
-                              top ? L.u.as<double>() : L.tmp.as<double>(), s->opt.omega, st));
+                              top ? L.u.as<double>() : L.tmp.as<double>(), s->opt.omega, st,
+                              ranged ? sb.up_lo[l] : 0, ranged ? sb.up_hi[l] : -1));
       continue;
     }
     // the last sweep of this level also prolongs into level l-1 when that fuses
@@ -1857,6 +1902,155 @@ amg_hip_status amg_hip_vcycles(amg_hip_solver* s, int32_t n) {
   return AMG_HIP_OK;
 }
 amg_hip_status amg_hip_vcycle(amg_hip_solver* s) { return amg_hip_vcycles(s, 1); }
+
+// ---- slab sharding (struct Slab) ---------------------------------------------
+namespace {
+// a bigger allocation with the same leading contents
+amg_hip_status grow(DevMem& m, size_t bytes, hipStream_t st) {
+  if (m.bytes >= bytes) return AMG_HIP_OK;
+  DevMem big;
+  HIP_TRY(big.alloc(bytes));
+  HIP_TRY(hipMemsetAsync(big.p, 0, bytes, st));
+  if (m.bytes) HIP_TRY(hipMemcpyAsync(big.p, m.p, m.bytes, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  m = std::move(big);
+  return AMG_HIP_OK;
+}
+}  // namespace
+
+amg_hip_status amg_hip_slab_plan(int64_t lines, int32_t rank, int32_t world, int32_t levels,
+                                 amg_hip_slab_info* out) {
+  if (!out || lines < 1 || world < 1 || rank < 0 || rank >= world || levels < 1 ||
+      levels > AMG_HIP_SLAB_MAX_LEVELS)
+    return fail(AMG_HIP_EINVAL, "amg_hip_slab_plan: bad argument");
+  const int k = levels;
+  std::memset(out, 0, sizeof(*out));
+  const int64_t chunk = (lines + world - 1) / world;
+  const int64_t line0 = std::min<int64_t>(lines, chunk * rank);
+  const int64_t line1 = std::min<int64_t>(lines, chunk * (rank + 1));
+  // Lines beyond the owned block on which each leg's INPUT has to be valid.  A Jacobi sweep or
+  // a residual makes one line plus one entry (the corner couplings of the 9-point coarse
+  // operators) at either end stale; the restriction and the prolongation reach two / one
+  // entries across a line end.  Counted in whole lines:
+  //   up-leg of level l (prolongation + two sweeps) has to leave u_l valid 3 l lines out (what
+  //   level l-1 loads: two sweeps' worth plus the neighbouring coarse entry), so the smoothed
+  //   u_l the down-leg left must be valid 3 l + 2 lines and 2 entries out: 3 l + 3 lines;
+  //   down-leg of level l: input valid I_l lines out gives f_{l+1} valid I_l - sweeps - 2 lines
+  //   out (sweeps, residual, and the restriction's entries: less than a line), where sweeps = 2
+  //   on level 0 and 1 below it (the first sweep of a coarser level is done by the finer
+  //   level's kernel); the gathered level needs f only on the owned lines.
+  std::vector<int64_t> need(k + 1, 0);
+  for (int l = k - 1; l >= 0; --l) {
+    const int sw = l == 0 ? 2 : 1;
+    const int64_t own = 3 * l + 3 + sw;
+    const int64_t feed = (l + 1 < k ? need[l + 1] : 0) + 2 + sw;
+    need[l] = std::max(own, feed);
+  }
+  const int64_t last = lines - chunk * (world - 1);
+  if (world > 1 && (last < need[0] || chunk < need[0]))
+    return fail(AMG_HIP_EUNSUPPORTED, "amg_hip_slab_plan: fewer grid lines per rank than the halo depth");
+  auto lo = [&](int64_t h) { return world == 1 ? 0 : std::max<int64_t>(0, line0 - h); };
+  auto hi = [&](int64_t h) { return world == 1 ? lines : std::min<int64_t>(lines, line1 + h); };
+  for (int l = 0; l < k; ++l) {
+    out->down_lo[l] = lo(need[l]);
+    out->down_hi[l] = hi(need[l]);
+    out->up_lo[l] = lo(3 * l);
+    out->up_hi[l] = hi(3 * l);
+  }
+  out->levels = k;
+  out->halo_lines = (int32_t)need[0];
+  out->lines = lines;
+  out->chunk_lines = chunk;
+  out->line_begin = line0;
+  out->line_end = line1;
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_slab_setup(amg_hip_solver* s, int32_t rank, int32_t world,
+                                  int32_t max_levels, amg_hip_slab_info* info) {
+  if (!s || !info || world < 1 || rank < 0 || rank >= world)
+    return fail(AMG_HIP_EINVAL, "amg_hip_slab_setup: bad argument");
+  amg_hip_status r = set_device(s);
+  if (r != AMG_HIP_OK) return r;
+  int k = 0;
+  while (patch_level_ok(s, k)) ++k;
+  if (max_levels >= 0 && k > max_levels) k = max_levels;
+  if (k > AMG_HIP_SLAB_MAX_LEVELS) k = AMG_HIP_SLAB_MAX_LEVELS;
+  if (k < 1)
+    return fail(AMG_HIP_EUNSUPPORTED,
+                "amg_hip_slab_setup: no K-Patch level (needs the 2+2 true-Jacobi cycle on a "
+                "dictionary-coded 2-D hierarchy of at least patch_min_rows rows)");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  Slab& sb = s->slab;
+  sb.reset_graphs();
+  const Level& L0 = s->lv[0];
+  const int64_t m0 = L0.A_rows.patch_m;
+  sb.lines = (L0.n + m0 - 1) / m0;
+  for (int l = 0; l <= k; ++l) {  // the lines of the slab levels coincide (x-only coarsening)
+    const Level& L = s->lv[l];
+    const int64_t m = l < k ? L.A_rows.patch_m : s->lv[k - 1].A_rows.patch_m / 2;
+    if (m != (m0 >> l) || (L.n + m - 1) / m != sb.lines)
+      return fail(AMG_HIP_EUNSUPPORTED, "amg_hip_slab_setup: level lines do not coincide");
+  }
+  amg_hip_slab_info pl;
+  if ((r = amg_hip_slab_plan(sb.lines, rank, world, k, &pl)) != AMG_HIP_OK) return r;
+  sb.rank = rank;
+  sb.world = world;
+  sb.chunk = pl.chunk_lines;
+  sb.line0 = pl.line_begin;
+  sb.line1 = pl.line_end;
+  sb.halo = pl.halo_lines;
+  sb.down_lo.assign(pl.down_lo, pl.down_lo + k);
+  sb.down_hi.assign(pl.down_hi, pl.down_hi + k);
+  sb.up_lo.assign(pl.up_lo, pl.up_lo + k);
+  sb.up_hi.assign(pl.up_hi, pl.up_hi + k);
+  sb.levels = k;
+  // in-place all-gathers need room for world equal blocks
+  Level& G = s->lv[k];
+  const int64_t mk = m0 >> k;
+  if ((r = grow(G.f, sizeof(double) * (size_t)(sb.chunk * world * mk), s->stream)) != AMG_HIP_OK) return r;
+  if ((r = grow(s->lv[0].u, sizeof(double) * (size_t)(sb.chunk * world * m0), s->stream)) != AMG_HIP_OK) return r;
+  if (s->graph_ready) {  // the whole-cycle graph holds the old pointers
+    (void)hipGraphExecDestroy(s->graph_exec);
+    (void)hipGraphDestroy(s->graph);
+    s->graph_exec = nullptr;
+    s->graph = nullptr;
+    s->graph_ready = false;
+  }
+  *info = pl;
+  info->pitch0 = m0;
+  info->gather_pitch = mk;
+  info->gather_rows = G.n;
+  info->u0 = s->lv[0].u.as<double>();
+  info->f_gather = G.f.as<double>();
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_slab_run(amg_hip_solver* s, int32_t part) {
+  if (!s || part < CYCLE_SLAB_DOWN || part > CYCLE_SLAB_UP)
+    return fail(AMG_HIP_EINVAL, "amg_hip_slab_run: part is 1 (down-legs), 2 (replicated rest) or 3 (up-legs)");
+  Slab& sb = s->slab;
+  if (sb.levels < 1) return fail(AMG_HIP_EINVAL, "amg_hip_slab_run: amg_hip_slab_setup has not succeeded");
+  amg_hip_status r = set_device(s);
+  if (r != AMG_HIP_OK) return r;
+  if (!s->opt.use_graph) return enqueue_vcycle(s, part);
+  const int gi = part - 1;
+  if (!sb.exec[gi]) {
+    HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    r = enqueue_vcycle(s, part);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(s->stream, &g);
+    if (r != AMG_HIP_OK) {
+      if (g) (void)hipGraphDestroy(g);
+      return r;
+    }
+    if (e != hipSuccess) return fail(AMG_HIP_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    sb.graph[gi] = g;
+    HIP_TRY(hipGraphInstantiate(&sb.exec[gi], g, nullptr, nullptr, 0));
+  }
+  HIP_TRY(hipGraphLaunch(sb.exec[gi], s->stream));
+  return AMG_HIP_OK;
+}
 
 amg_hip_status amg_hip_sync(amg_hip_solver* s) {
   if (!s) return fail(AMG_HIP_EINVAL, "null solver");

@@ -217,6 +217,48 @@ amg_hip_status amg_hip_vcycles(amg_hip_solver* s, int32_t n);
 /* Block until the solver's stream is idle. */
 amg_hip_status amg_hip_sync(amg_hip_solver* s);
 
+/* ---- row-block ("slab") sharding of one V-cycle over several GPUs ---------
+ * The reference is a serial program (multigrid.hpp:263-305 walks whole levels); this is the
+ * build's multi-GPU form of that loop.  Every rank creates the SAME solver (whole hierarchy,
+ * full-size vectors) and then runs the K-Patch levels 0..levels-1 only over its own block of
+ * grid lines plus `halo_lines` lines either side, recomputed redundantly, so that the whole
+ * cycle needs two exchanges, both done by the caller (RCCL / torch.distributed) on the
+ * solver's stream:
+ *   1. before part 1: lines [line_begin - halo_lines, line_begin) and [line_end, line_end +
+ *      halo_lines) of u0 from the two neighbouring ranks (their owned lines, same offsets);
+ *   2. between parts 1 and 2: all-gather of f_gather, rank g contributing the entries
+ *      [g, g+1) * chunk_lines * gather_pitch (equal blocks; the allocation has room for
+ *      world of them, entries past gather_rows are padding);
+ * part 2 (levels >= `levels`, coarse solve included) runs replicated on every rank.  After
+ * part 3 each rank holds its own lines of the level-0 solution; per-row arithmetic is the
+ * single-GPU cycle's, so the assembled solution equals it bit for bit.
+ * amg_hip_slab_plan is the pure host arithmetic (no device): per slab level l the lines
+ * [down_lo[l], down_hi[l]) the down-leg runs over and [up_lo[l], up_hi[l]) for the up-leg. */
+#define AMG_HIP_SLAB_MAX_LEVELS 8
+typedef struct amg_hip_slab_info {
+  int32_t levels;      /* slab levels (0 .. levels-1); level `levels` is the gathered one   */
+  int32_t halo_lines;  /* lines of u0 each neighbour supplies before a cycle                */
+  int64_t lines;       /* grid lines (the same on every slab level: x-only coarsening)      */
+  int64_t chunk_lines; /* lines per rank = ceil(lines / world); the last rank may own fewer  */
+  int64_t line_begin, line_end; /* this rank's lines                                        */
+  int64_t pitch0;       /* entries per line on level 0                                      */
+  int64_t gather_pitch; /* entries per line on level `levels`                               */
+  int64_t gather_rows;  /* rows of level `levels`                                           */
+  int64_t down_lo[AMG_HIP_SLAB_MAX_LEVELS], down_hi[AMG_HIP_SLAB_MAX_LEVELS];
+  int64_t up_lo[AMG_HIP_SLAB_MAX_LEVELS], up_hi[AMG_HIP_SLAB_MAX_LEVELS];
+  double* u0;           /* device: level-0 solution, room for world*chunk_lines*pitch0      */
+  double* f_gather;     /* device: rhs of level `levels`, room for world*chunk_lines*gather_pitch */
+} amg_hip_slab_info;
+/* AMG_HIP_EUNSUPPORTED when a rank would own fewer lines than the halo depth. */
+amg_hip_status amg_hip_slab_plan(int64_t lines, int32_t rank, int32_t world, int32_t levels,
+                                 amg_hip_slab_info* out);
+/* max_levels < 0: every K-Patch level.  AMG_HIP_EUNSUPPORTED when the solver has none.     */
+amg_hip_status amg_hip_slab_setup(amg_hip_solver* s, int32_t rank, int32_t world,
+                                  int32_t max_levels, amg_hip_slab_info* info);
+/* part 1: down-legs of the slab levels; 2: the replicated rest of the cycle (from the gathered
+ * rhs); 3: up-legs of the slab levels.  Asynchronous on the solver's stream (one hipGraph each). */
+amg_hip_status amg_hip_slab_run(amg_hip_solver* s, int32_t part);
+
 /* Multigrid::solve(), multigrid.hpp:311-337: while (iter < n_iters && error >
  * tol) { vcycle(); if (++iter % every == 0) error = rss }.  error starts at 100.
  * *converged = (error <= tol).  Prints nothing (the C++ layer prints the

@@ -240,3 +240,113 @@ def test_transport_watchdog_exits_nonzero_and_names_the_transport():
     code2 = code.replace("time.sleep(20)", "w.disarm(); time.sleep(0.6)")
     p = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "not reached" in p.stdout
+
+
+# ---- slab sharding (algebraic-multigrid_amd/slab_vcycle.py) ---------------------------------
+def _slab_worker(rank, world, port, n, L, levels, cycles, out_dir, tamper, gpu=False):
+    for p in (ROOT, os.path.join(ROOT, "algebraic-multigrid_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    import amg_ctypes as amg
+    import slab_vcycle
+    from slab_engine import EmulatedSlabEngine
+    if gpu:   # the real engine on device 0, exchanges staged through gloo
+        amg.set_patch_min_rows(0)
+        dev = torch.device("cuda", 0)
+        st = torch.cuda.Stream(dev)
+        torch.cuda.set_stream(st)
+        eng = slab_vcycle.HipSlabEngine(amg, dev, st, n, L, 0.6, 2, rank, world, levels)
+    else:
+        eng = EmulatedSlabEngine(O, amg, n, L, 0.6, rank, world, levels, tamper=tamper)
+    dv = slab_vcycle.SlabVcycle(eng, rank, world, host_staged=gpu)
+    rss = []
+    for _ in range(cycles):
+        dv.vcycle()
+        rss.append(dv.rss())
+    u = dv.gather_solution()
+    if not tamper:
+        assert dv.solution_checksum() == int(np.ascontiguousarray(u).view(np.int64).sum(dtype=np.int64))
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "slab.npz"), u=u, rss=np.array(rss), n_dist=dv.n_dist,
+                 halo=int(eng.info.halo_lines))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_slab(tmp_path, world, n, L, levels, cycles, tamper=0, gpu=False):
+    port = _free_port()
+    mp.spawn(_slab_worker, args=(world, port, n, L, levels, cycles, str(tmp_path), tamper, gpu),
+             nprocs=world, join=True)
+    return np.load(os.path.join(str(tmp_path), "slab.npz"))
+
+
+@pytest.mark.parametrize("world,levels", [(1, 2), (2, 2), (3, 2), (2, 3), (3, 1)])
+def test_slab_sharded_vcycle_equals_single_process(tmp_path, oracle, world, levels):
+    """Two exchanges per cycle (halo lines of u_0, all-gather of the first replicated level's
+    rhs) and redundantly recomputed halos: every entry the plan does not promise is NaN in the
+    emulated engine, so the bit-equality below also proves the halo depths of
+    amg_hip_slab_plan are sufficient."""
+    n, L, cycles = 128, 7, 3
+    got = _run_slab(tmp_path, world, n, L, levels, cycles)
+    assert int(got["n_dist"]) == (levels if world > 1 else 0)
+    ref = oracle.Multigrid(oracle.laplacian(n), oracle.rhs(n), L, smoother=oracle.SM_TRUE_JACOBI,
+                           smoother_iters=2, omega=0.6)
+    for c in range(cycles):
+        ref.vcycle()
+        assert got["rss"][c] == ref.rss()       # assembled vector, same reduction: same bits
+    assert np.array_equal(got["u"], ref.get_vec(0, "u"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_sharded_vcycle_hip_engine_on_one_gpu(tmp_path, oracle, world):
+    """slab_vcycle.SlabVcycle + HipSlabEngine (amg_hip_slab_setup / amg_hip_slab_run), one
+    process per rank, all on GPU 0, exchanges staged through gloo: against the oracle twin."""
+    n, L, cycles = 512, 8, 3
+    got = _run_slab(tmp_path, world, n, L, -1, cycles, gpu=True)
+    assert int(got["n_dist"]) == 3 and int(got["halo"]) == 17
+    ref = oracle.Multigrid(oracle.laplacian(n), oracle.rhs(n), L, smoother=oracle.SM_TRUE_JACOBI,
+                           smoother_iters=2, omega=0.6)
+    for c in range(cycles):
+        ref.vcycle()
+        assert abs(got["rss"][c] - ref.rss()) <= 1e-12 * ref.rss()      # tree sum on the device
+    assert np.array_equal(got["u"], ref.get_vec(0, "u"))
+
+
+def test_slab_halo_depth_is_tight_enough_to_matter(tmp_path, oracle):
+    """The same run with every leg's range and the exchanged halo three lines shallower must NOT
+    reproduce the single-process result (else the test above would prove nothing).  The plan
+    counts whole lines at every level boundary, which leaves up to one line of slack per slab
+    level: with two slab levels, two lines less still work and three do not."""
+    n, L, cycles = 128, 7, 2
+    got = _run_slab(tmp_path, 2, n, L, 2, cycles, tamper=3)
+    ref = oracle.Multigrid(oracle.laplacian(n), oracle.rhs(n), L, smoother=oracle.SM_TRUE_JACOBI,
+                           smoother_iters=2, omega=0.6)
+    for _ in range(cycles):
+        ref.vcycle()
+    assert not np.array_equal(got["u"], ref.get_vec(0, "u"))
+
+
+def test_slab_plan_arithmetic():
+    sys.path.insert(0, os.path.join(ROOT, "algebraic-multigrid_amd"))
+    import amg_ctypes as amg
+    for world in (1, 2, 5, 8):
+        prev_end = 0
+        for r in range(world):
+            i = amg.slab_plan(4096, r, world, 4)
+            assert i.line_begin == prev_end and i.levels == 4
+            prev_end = i.line_end
+            assert i.halo_lines == 23                       # 6 k - 1 lines for k = 4 slab levels
+            for l in range(4):
+                assert i.down_lo[l] <= i.up_lo[l] <= i.line_begin <= i.line_end <= i.up_hi[l] <= i.down_hi[l]
+                if l:
+                    assert i.down_lo[l] >= i.down_lo[l - 1] and i.down_hi[l] <= i.down_hi[l - 1]
+            if world > 1 and 0 < r < world - 1:
+                assert i.down_lo[0] == i.line_begin - 23 and i.up_lo[3] == i.line_begin - 9
+        assert prev_end == 4096
+    with pytest.raises(amg.AmgHipError):
+        amg.slab_plan(64, 0, 4, 4)                          # 16 lines per rank < 23
