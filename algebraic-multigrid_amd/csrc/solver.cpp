@@ -759,8 +759,11 @@ struct Slab {
   }
 };
 
+int64_t g_patch_min_rows = (int64_t)1 << 20;  // amg_hip_set_patch_min_rows
+
 struct amg_hip_solver {
   amg_hip_options opt;
+  int64_t patch_min_rows = g_patch_min_rows;  // the process-wide value when the solver was made
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = true;
@@ -817,14 +820,13 @@ bool fuses_resid_restrict(const amg_hip_solver* s, int l) {
 // K-Patch: the whole down-leg / up-leg of a big level in one launch each (kernels.hip).
 // Levels 0 .. k of a 2+2 true-Jacobi cycle whose matrices are row-typed dictionaries with a
 // 2-D band (the finer level's kernel hands the first sweep of the next one over).
-int64_t g_patch_min_rows = (int64_t)1 << 20;
 bool patch_level_ok(const amg_hip_solver* s, int l) {
   if (l < 0 || l + 2 >= (int)s->lv.size()) return false;  // needs a smoothed coarser level
   const Level& L = s->lv[l];
   const DevMat& A = L.A_rows;
   if (!(jacobi_fuses_zero(s) && !s->opt.fuse_prolong && s->opt.smoother_iters == 2 && L.symmetric &&
         A.dict && A.dict_shift == 0 && A.patch && L.linear && s->opt.stencil_transfers &&
-        L.n >= g_patch_min_rows && s->lv[l + 1].diag.p != nullptr))
+        L.n >= s->patch_min_rows && s->lv[l + 1].diag.p != nullptr))
     return false;
   return l == 0 || patch_level_ok(s, l - 1);
 }
@@ -2407,13 +2409,16 @@ amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
   // level's whole down-leg (2 sweeps + residual + restriction + first coarse sweep); it also
   // rewrites f and tmp of level 1, which every V-cycle recomputes before use.
   const bool patch = patch_level_ok(s, 0);
+  // slab-sharded solver: this rank's launch, i.e. its own lines + halo only
+  const bool slab = patch && s->slab.levels > 0 && s->slab.world > 1;
   for (int i = 0; i < n_launches; ++i) {
     HIP_TRY(hipEventRecord(ev[2 * i], s->stream));
     if (patch) {
       Level& C = s->lv[1];
       HIP_TRY(launch_patch_down(true, L.n, A.patch_m, A.patch_ref(), L.u.as<double>(),
                                 L.f.as<double>(), L.tmp.as<double>(), nullptr, C.n, C.f.as<double>(),
-                                C.diag.as<double>(), C.tmp.as<double>(), s->opt.omega, s->stream));
+                                C.diag.as<double>(), C.tmp.as<double>(), s->opt.omega, s->stream,
+                                slab ? s->slab.down_lo[0] : 0, slab ? s->slab.down_hi[0] : -1));
     } else {
       HIP_TRY(launch_mat(CSR_JACOBI, A, L.u.as<double>(), L.f.as<double>(), L.tmp.as<double>(),
                          s->opt.omega, s->stream));
@@ -2452,6 +2457,12 @@ amg_hip_status amg_hip_fine_sweep_info(const amg_hip_solver* s, char* name, int3
                   A.dict_nt ? "true" : "false");
     sweeps = 2;
     bytes = 25.0 * (double)L.n + 24.0 * (double)s->lv[1].n;
+    if (s->slab.levels > 0 && s->slab.world > 1) {  // the tiles this rank's launch covers
+      const int64_t th = patch_tile_lines();
+      const int64_t l0 = s->slab.down_lo[0] / th * th;
+      const int64_t l1 = std::min<int64_t>(s->slab.lines, (s->slab.down_hi[0] + th - 1) / th * th);
+      bytes *= (double)(l1 - l0) / (double)s->slab.lines;
+    }
   } else if (A.dict) {
     dict_kernel_name(CSR_JACOBI, A.n_rows, A.dict_ref(), L.f.p, L.tmp.p, name, (size_t)name_cap);
     bytes = (double)mat + 24.0 * (double)L.n;  // matrix stream (1 B / row) + f + x + out

@@ -981,7 +981,40 @@ def bench(args):
             notes["replicated"] = "did not reproduce the sharded result; discarded"
         notes["replicated_distributed_levels"] = dvr.n_dist
 
-    if dv.n_dist and args.comm not in ("p2p", "safe"):
+    # Slab sharding (slab_vcycle.py): the K-Patch levels over this rank's grid lines + redundant
+    # halo, two exchanges per cycle (grouped send/recv of the level-0 halo lines, one all-gather),
+    # the rest replicated.  Same RCCL primitives as "p2p"; kept only if it reproduces its result.
+    dvs = None
+    if world > 1 and args.comm in ("safe", "auto", "slab") and args.sweeps == 2:
+        import json as _json
+        import slab_vcycle
+        stash["json"] = _json.dumps(_result_line(args, world, L, dv, results, min(results, key=lambda k: results[k][0]),
+                                                 dict(notes, note="slab exchange hung"), rehearsal, None, None, t0)) if rank == 0 else None
+        stash["dv"], stash["n_dist"] = None, None
+        dog.arm("slab")
+        try:
+            if os.environ.get("AMG_DIST_FORCE_HANG") == "slab":
+                time.sleep(args.comm_timeout + 30)
+            eng = slab_vcycle.HipSlabEngine(amg, be.device, be._stream, args.n, L, args.omega, args.sweeps,
+                                            rank, world, args.slab_levels,
+                                            patch_min_rows=args.slab_patch_min_rows)
+            dvs = slab_vcycle.SlabVcycle(eng, rank, world, host_staged=rehearsal)
+            notes["slab_distributed_levels"] = dvs.n_dist
+            notes["slab_halo_lines"] = int(eng.info.halo_lines)
+            res = timed(dvs)
+            if same_result(res, results["p2p"]):
+                results["slab"] = res
+                notes["slab"] = "ok"
+            else:
+                notes["slab"] = "ran but did not reproduce the p2p result; discarded"
+        except amg.AmgHipError as ex:
+            if ex.status != amg.EUNSUPPORTED:
+                raise
+            notes["slab"] = f"unavailable: {ex.message}"   # the same refusal on every rank (host arithmetic)
+        finally:
+            dog.disarm()
+
+    if dv.n_dist and args.comm not in ("p2p", "safe", "slab"):
         import json as _json
         stash["json"] = _json.dumps(_result_line(args, world, L, dv, results, "p2p", {"note": "alternative exchange hung"},
                                                  rehearsal, None, None, t0)) if rank == 0 else None
@@ -1040,14 +1073,15 @@ def bench(args):
     best_nd = dv.n_dist if best == "p2p" else notes.get(best + "_distributed_levels")
     whole = (dv if dv.n_dist == 0 else dvr) if best_nd == 0 else None
     roof_whole = None
-    if whole is not None and hasattr(whole.tail, "mg"):
+    if best == "slab" or (whole is not None and hasattr(whole.tail, "mg")):
         from bench import fine_sweep_roofline
-        mgw = whole.tail.mg
+        mgw = dvs.eng.mg if best == "slab" else whole.tail.mg
         lay_id, mat_b = mgw.level_layout(0)
         lay_nm = {amg.LAYOUT_CSR: "csr", amg.LAYOUT_SELL: "sell", amg.LAYOUT_DICT: "dict"}[lay_id]
         roof_whole = fine_sweep_roofline(amg, mgw, args, lay_nm, mat_b, mgw.get_n_dofs(0), mgw.cycle_bytes()[1],
                                          launches=max(8, args.profile_launches // 2))
-        roof_whole["note"] = "per rank: every rank runs the whole cycle (nothing is distributed)"
+        roof_whole["note"] = ("per rank: rank 0's lines + halo of the level-0 down-leg (slab sharding)" if best == "slab"
+                              else "per rank: every rank runs the whole cycle (nothing is distributed)")
     out = None
     if rank == 0:
         if args.warmup >= 1 and not (rss < rss0):
@@ -1062,6 +1096,8 @@ def bench(args):
             out["roofline"] = roof_whole
     if dvr is not None:
         dvr.close()
+    if dvs is not None:
+        dvs.close()
     dist.barrier()
     dist.destroy_process_group()
     return out

@@ -148,10 +148,21 @@ class HipSlabEngine:
     """The C-ABI solver (libamg_hip.so) as the engine: amg_hip_create_poisson on this rank's
     GPU, amg_hip_slab_setup / amg_hip_slab_run; u0 and fg are torch views of its memory."""
 
-    def __init__(self, amg, device, stream, n, n_levels, omega, sweeps, rank, world, max_levels=-1):
+    def __init__(self, amg, device, stream, n, n_levels, omega, sweeps, rank, world, max_levels=-1,
+                 patch_min_rows=None):
+        """patch_min_rows: K-Patch threshold for THIS solver (amg_hip_set_patch_min_rows is read
+        when a solver is created; the default is restored afterwards).  A sharded level is
+        1/world of the work per rank, so smaller levels pay off as slab levels than as K-Patch
+        levels of a single GPU."""
         self.amg = amg
-        self.mg = amg.Multigrid.poisson(n, n_levels, smoother=amg.SM_JACOBI, smoother_iters=sweeps,
-                                        omega=omega, device=device.index, stream=stream.cuda_stream)
+        if patch_min_rows is not None:
+            amg.set_patch_min_rows(patch_min_rows)
+        try:
+            self.mg = amg.Multigrid.poisson(n, n_levels, smoother=amg.SM_JACOBI, smoother_iters=sweeps,
+                                            omega=omega, device=device.index, stream=stream.cuda_stream)
+        finally:
+            if patch_min_rows is not None:
+                amg.set_patch_min_rows(1 << 20)
         try:
             self.info = self.mg.slab_setup(rank, world, max_levels)
         except Exception:

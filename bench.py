@@ -290,14 +290,22 @@ def main():
                     help="grid of the CPU baseline sample (0 = the benchmarked --grid itself)")
     ap.add_argument("--cpu-cycles", type=int, default=3)
     ap.add_argument("--profile-launches", type=int, default=40)
-    ap.add_argument("--comm", choices=["safe", "auto", "p2p", "ipc", "graph"], default="safe",
-                    help="multi-GPU halo exchange.  safe (default) = the two configurations that "
-                         "cannot hang: p2p (torch.distributed isend/irecv over RCCL) and replicated "
-                         "(nothing distributed); the faster one is reported.  auto = additionally "
+    ap.add_argument("--comm", choices=["safe", "auto", "p2p", "slab", "ipc", "graph"], default="safe",
+                    help="multi-GPU halo exchange.  safe (default) = the configurations built on "
+                         "plain RCCL calls only: slab (K-Patch levels over each rank's grid lines + "
+                         "redundant halo: one grouped send/recv and one all-gather per cycle), p2p "
+                         "(a send/recv before every sweep, residual and transfer) and replicated "
+                         "(nothing distributed); the fastest one is reported.  auto = additionally "
                          "ipc (hipIpc pushes + stream memory ops) and graph (pushes + flags as "
                          "kernels, one hipGraph per rank): experimental, never run on real xGMI "
                          "links; bounded by a watchdog that exits with status 3 when one hangs.  "
                          "Every candidate must reproduce the p2p result bit for bit")
+    ap.add_argument("--slab-levels", type=int, default=-1,
+                    help="slab sharding: number of K-Patch levels cut into row blocks (-1 = all of them)")
+    ap.add_argument("--slab-patch-min-rows", type=int, default=0,
+                    help="slab sharding: K-Patch threshold of the sharded solver (0 = every level whose "
+                         "lines are at least 128 entries long: each rank only runs 1/N of a slab level; "
+                         "compute-only estimates in tools/slab_estimate.py)")
     ap.add_argument("--dist-min-rows-ipc", type=int, default=5000000)
     ap.add_argument("--dist-min-rows-graph", type=int, default=250000)
     ap.add_argument("--comm-timeout", type=float, default=180.0,

@@ -68,4 +68,4 @@ def test_multi_gpu_default_is_the_safe_transport_set():
     finally:
         sys.argv = argv
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert 'choices=["safe", "auto", "p2p", "ipc", "graph"], default="safe"' in src
+    assert 'choices=["safe", "auto", "p2p", "slab", "ipc", "graph"], default="safe"' in src
