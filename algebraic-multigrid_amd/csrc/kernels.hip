@@ -908,8 +908,8 @@ constexpr int PATCH_TW = 64;                 // columns of a patch (output)
 constexpr int PATCH_TH = 42;                 // lines of a patch (output)
 constexpr int PATCH_EH = PATCH_TH + 6;       // lines held, 3 rings
 constexpr int PATCH_EC = PATCH_TW + 8;       // columns held: [-4, TW + 4)
-constexpr int PATCH_NT = 576;                // threads = 8 line groups x 72 columns
-constexpr int PATCH_K = PATCH_EH * PATCH_EC / PATCH_NT;  // cells per thread: 6 consecutive lines
+constexpr int PATCH_NT = 432;                // threads = 6 line groups x 72 columns (4 workgroups per CU)
+constexpr int PATCH_K = PATCH_EH * PATCH_EC / PATCH_NT;  // cells per thread: 8 consecutive lines
 constexpr int PATCH_BUF = (PATCH_EH + 2) * PATCH_EC;     // + one guard line above and below
 constexpr int PATCH_MAXTAB = 192;            // table capacity: (types + 1) x slots
 static_assert(PATCH_EH * PATCH_EC == PATCH_K * PATCH_NT && PATCH_NT % PATCH_EC == 0, "patch geometry");
@@ -917,7 +917,7 @@ static_assert(PATCH_EH * PATCH_EC == PATCH_K * PATCH_NT && PATCH_NT % PATCH_EC =
 struct PatchJ { double a, d; };              // off-diagonal value (else +0.0), diagonal value (else +0.0)
 struct PatchR { double a; int32_t loff, ok; };  // value, LDS offset, slot in use
 
-// The PATCH_K cells one thread owns: column li of the consecutive lines lj0 .. lj0 + 5; cell k
+// The PATCH_K cells one thread owns: column li of the consecutive lines lj0 .. lj0 + 7; cell k
 // sits at LDS index cell0 + k * PATCH_EC and is flat row row0 + k m.  Adjacent lanes own
 // adjacent columns (conflict-free 8-byte LDS accesses, coalesced global ones), and a thread's
 // cells are vertical neighbours, so the wave-uniform path walks them with a sliding 3 x 3
@@ -1068,7 +1068,7 @@ __device__ __forceinline__ double patch_eval(const double* buf, int cell, uint32
 // one stage over the region lines [l0, l1) x columns [c0, c1), IN PLACE in the workgroup's one
 // LDS buffer: every thread evaluates its PATCH_K cells into registers (branch-free, so the
 // LDS reads overlap), the workgroup meets at a barrier, then the results are written back
-// (one buffer instead of two: three workgroups fit a CU instead of one, which is what these
+// (one buffer instead of two: four workgroups of 432 threads fit a CU instead of one, which is what these
 // latency-bound stages need).  Cells outside the region or outside the matrix keep their
 // value; ZERO: such cells inside the region are set to 0.0 instead (the residual that the
 // restriction reads).  out (optional): rows of the patch proper also go to global memory.
@@ -1199,7 +1199,7 @@ __device__ __forceinline__ void patch_prologue(const PatchCells& pc, double* buf
 // FIRST: the input is the level's u and both pre-sweeps run here (level 0); else the input
 // is the result of the first sweep (done by the finer level's kernel) and one sweep runs.
 template <int UN, bool FIRST, bool NT>
-__global__ __launch_bounds__(PATCH_NT) void patch_down_kernel(
+__global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
     int nent, int ntypes, const double* x, const double* __restrict__ f, double* u_out, double* r_out, int nH,
@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(PATCH_NT) void patch_down_kernel(
 }
 
 template <int UN, bool NT>
-__global__ __launch_bounds__(PATCH_NT) void patch_up_kernel(
+__global__ __launch_bounds__(PATCH_NT, 7) void patch_up_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
     int nent, int ntypes, const double* x, const double* __restrict__ f, const double* __restrict__ uH, int nH,

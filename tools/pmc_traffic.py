@@ -31,10 +31,10 @@ PITCH = [4096, 2048, 1024, 512, 256]
 
 
 def patch_grid(l):
-    """threads of a K-Patch launch on level l: tiles of 42 lines x 64 columns, 576 threads each"""
+    """threads of a K-Patch launch on level l: tiles of 42 lines x 64 columns, 432 threads each"""
     n, m = LEVEL_ROWS[l], PITCH[l]
     lines = (n + m - 1) // m
-    return ((lines + 41) // 42) * (m // 64) * 576
+    return ((lines + 41) // 42) * (m // 64) * 432
 
 
 def classify(name, grid):
