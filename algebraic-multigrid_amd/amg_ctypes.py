@@ -120,6 +120,8 @@ _SIGS = {
     "amg_hip_coarse_solve_kind": (C.c_int32, [C.c_void_p]),
     "amg_hip_fine_sweep_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _i32p, _f64p]),
     "amg_hip_set_patch_min_rows": (None, [C.c_int64]),
+    "amg_hip_create_rs": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_int32, C.c_double, C.c_int64,
+                                    C.POINTER(Options), C.POINTER(C.c_void_p)]),
     "amg_hip_slab_plan": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(SlabInfo)]),
     "amg_hip_slab_setup": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(SlabInfo)]),
     "amg_hip_slab_run": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -374,6 +376,34 @@ class Multigrid:
         if stream:
             o.stream = C.c_void_p(stream)
         return o
+
+    @classmethod
+    def ruge_stueben(cls, colptr, rowind, val, b, max_levels=25, theta=0.25, min_coarse=500,
+                     smoother=SM_SPGS, smoother_iters=1, omega=1.0, tolerance=1e-9,
+                     compute_error_every_n_iters=10, n_iters=100, device=-1, use_graph=True, layout=None,
+                     host_only=False, stream=None, host_galerkin=False, exact_coarse_solve=False,
+                     exact_gs=False):
+        """AMG::Multigrid on a strength-based C/F hierarchy (amg_hip_create_rs): same V-cycle,
+        coarsening by the classical Ruge-Stueben first pass with direct interpolation.
+        `self.n_levels` tells how many levels were built."""
+        colptr, rowind, val, b = _a32(colptr), _a32(rowind), _a64(val), _a64(b)
+        n = colptr.size - 1
+        if n != b.size:
+            raise ValueError("`A` and `b` must have the same number of degrees of freedom, "
+                             f"got {n} and {b.size}")
+        self = cls.__new__(cls)
+        self.tolerance, self.every, self.n_iters = tolerance, compute_error_every_n_iters, n_iters
+        o = cls._options(smoother, smoother_iters, omega, device, use_graph, True, layout, host_only,
+                         False, False, False, stream, False, host_galerkin, False, exact_coarse_solve,
+                         exact_gs)
+        h = C.c_void_p()
+        st = lib().amg_hip_create_rs(n, _p32(colptr), _p32(rowind), _p64(val), _p64(b), int(max_levels),
+                                     float(theta), int(min_coarse), C.byref(o), C.byref(h))
+        if st == EINVAL:
+            raise ValueError(lib().amg_hip_last_error().decode())
+        _chk(st)
+        self._h = h
+        return self
 
     @classmethod
     def poisson(cls, n, n_levels, dim=2, smoother=SM_SPGS, smoother_iters=1, omega=1.0, tolerance=1e-9,

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <climits>
 #include <map>
+#include <queue>
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -869,6 +870,123 @@ void rhs(int dim, int64_t n, double* b) {
   int64_t N = n * n;
   if (dim == 3) N *= n;
   rhs_range(dim, n, b, 0, N);
+}
+
+
+// ---- strength-based C/F coarsening (host_setup.hpp) -----------------------------------
+Sparse ruge_stueben_P(const Sparse& A, double theta, std::vector<uint8_t>* is_c_out) {
+  const int64_t n = A.n_outer;
+  // strength graph S (CSR, column indices ascending like A's) and its transpose
+  std::vector<int32_t> sp(n + 1, 0), stp(n + 1, 0);
+  std::vector<int32_t> sj;
+  sj.reserve((size_t)A.nnz());
+  std::vector<double> sgn(n, 1.0);
+  for (int64_t i = 0; i < n; ++i) {
+    double d = 0.0;
+    for (int32_t p = A.ptr[i]; p < A.ptr[i + 1]; ++p)
+      if (A.idx[p] == i) d = A.val[p];
+    sgn[i] = d < 0.0 ? -1.0 : 1.0;
+    double mx = 0.0;
+    for (int32_t p = A.ptr[i]; p < A.ptr[i + 1]; ++p)
+      if (A.idx[p] != i) mx = std::max(mx, -sgn[i] * A.val[p]);
+    if (mx > 0.0) {
+      const double thr = theta * mx;
+      for (int32_t p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+        const double sij = -sgn[i] * A.val[p];
+        if (A.idx[p] != i && sij > 0.0 && sij >= thr) {
+          sj.push_back(A.idx[p]);
+          ++stp[A.idx[p] + 1];
+        }
+      }
+    }
+    sp[i + 1] = (int32_t)sj.size();
+  }
+  for (int64_t i = 0; i < n; ++i) stp[i + 1] += stp[i];
+  std::vector<int32_t> stj(sj.size());
+  {
+    std::vector<int32_t> fill(stp.begin(), stp.end() - 1);
+    for (int64_t i = 0; i < n; ++i)
+      for (int32_t p = sp[i]; p < sp[i + 1]; ++p) stj[fill[sj[p]]++] = (int32_t)i;
+  }
+  // first pass
+  enum : uint8_t { U = 0, C = 1, F = 2 };
+  std::vector<uint8_t> st(n, U);
+  std::vector<int32_t> lam(n);
+  using Key = std::pair<int32_t, int32_t>;  // (measure, -index): max measure, then lowest index
+  std::priority_queue<Key> heap;
+  for (int64_t i = 0; i < n; ++i) {
+    lam[i] = stp[i + 1] - stp[i];
+    if (sp[i + 1] == sp[i]) st[i] = F;  // no strong coupling: nothing to interpolate from
+    else heap.emplace(lam[i], -(int32_t)i);
+  }
+  while (!heap.empty()) {
+    const Key top = heap.top();
+    heap.pop();
+    const int32_t i = -top.second;
+    if (st[i] != U || lam[i] != top.first) continue;  // stale entry
+    st[i] = C;
+    for (int32_t p = stp[i]; p < stp[i + 1]; ++p) {
+      const int32_t j = stj[p];
+      if (st[j] != U) continue;
+      st[j] = F;
+      for (int32_t q = sp[j]; q < sp[j + 1]; ++q) {
+        const int32_t k = sj[q];
+        if (st[k] == U) heap.emplace(++lam[k], -k);
+      }
+    }
+    for (int32_t p = sp[i]; p < sp[i + 1]; ++p) {
+      const int32_t j = sj[p];
+      if (st[j] == U) heap.emplace(--lam[j], -j);
+    }
+  }
+  // coarse numbering and direct interpolation, row-wise (CSR(P)), then to CSC
+  std::vector<int32_t> cidx(n, -1);
+  int32_t nc = 0;
+  for (int64_t i = 0; i < n; ++i)
+    if (st[i] == C) cidx[i] = nc++;
+  Sparse Pr;  // CSR(P): n x nc
+  Pr.n_outer = n;
+  Pr.n_inner = nc;
+  Pr.ptr.assign(n + 1, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    if (st[i] == C) {
+      Pr.idx.push_back(cidx[i]);
+      Pr.val.push_back(1.0);
+    } else {
+      double num = 0.0, den = 0.0, dg = 0.0;
+      for (int32_t p = A.ptr[i]; p < A.ptr[i + 1]; ++p)
+        if (A.idx[p] == i) dg = A.val[p];
+      for (int32_t p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+        if (A.idx[p] == i) continue;
+        const double sij = -sgn[i] * A.val[p];
+        if (sij > 0.0) num += A.val[p];
+        else if (sij < 0.0) dg += A.val[p];
+      }
+      for (int32_t q = sp[i]; q < sp[i + 1]; ++q)
+        if (st[sj[q]] == C) {
+          // the value of a_{i, sj[q]}: S keeps A's column order, walk A alongside
+          for (int32_t p = A.ptr[i]; p < A.ptr[i + 1]; ++p)
+            if (A.idx[p] == sj[q]) den += A.val[p];
+        }
+      if (den != 0.0 && dg != 0.0) {
+        const double alpha = num / den;
+        for (int32_t q = sp[i]; q < sp[i + 1]; ++q) {
+          if (st[sj[q]] != C) continue;
+          double aij = 0.0;
+          for (int32_t p = A.ptr[i]; p < A.ptr[i + 1]; ++p)
+            if (A.idx[p] == sj[q]) aij = A.val[p];
+          Pr.idx.push_back(cidx[sj[q]]);
+          Pr.val.push_back(-alpha * aij / dg);
+        }
+      }
+    }
+    Pr.ptr[i + 1] = (int32_t)Pr.idx.size();
+  }
+  if (is_c_out) {
+    is_c_out->assign(n, 0);
+    for (int64_t i = 0; i < n; ++i) (*is_c_out)[i] = st[i] == C;
+  }
+  return transpose(Pr);  // CSC(P): n_outer = nc columns, n_inner = n rows
 }
 
 }  // namespace amg_hip

@@ -37,6 +37,20 @@ bool is_linear_P(const Sparse& P, int64_t n_h, int64_t n_H);
 // multigrid.hpp:127-130
 inline int64_t coarse_dofs(int64_t n_h) { return (n_h + 1) / 2 - 1; }
 
+// Strength-based C/F coarsening with direct interpolation (classical Ruge-Stueben first pass;
+// the alternative the reference names and does not build, README.md:104-109).  A_rows: CSR(A).
+// Couplings are measured against the sign of the diagonal (the reference's operators are
+// NEGATIVE definite: diagonal < 0, couplings > 0): s_ij = -sign(a_ii) a_ij; row i depends
+// strongly on j when s_ij > 0 and s_ij >= theta * max_k s_ik.  First pass: repeatedly make
+// the undecided point with the most strong dependants (ties: lowest index) a C point, its
+// undecided dependants F points, and raise / lower the measures of their neighbours.  Points
+// without strong couplings are F points with an empty row.  Direct interpolation for an F
+// point i over C_i = its strong C neighbours, sums in ascending column order:
+//   w_ij = -(sum_{k: s_ik > 0} a_ik / sum_{k in C_i} a_ik) * a_ij / (a_ii + sum_{k: s_ik < 0} a_ik).
+// Returns P in CSC (n_h x n_H, C points numbered in ascending fine index); R = transpose(P).
+// is_c (optional): 1 for C points.
+Sparse ruge_stueben_P(const Sparse& A_rows, double theta, std::vector<uint8_t>* is_c = nullptr);
+
 // C = A * B, all three in row-major CSR, Gustavson row by row.  For a fixed
 // output entry (i, J) the products are added in ascending k, which is the
 // order Eigen's conservative column-major product uses (multigrid.hpp:222);

@@ -408,7 +408,10 @@ hipError_t launch_sell_gs_color(int64_t n_storage, int /*idx16: rows are permute
                                 hipStream_t st) {
   if (count <= 0) return hipSuccess;
   if (n_storage >= ((int64_t)1 << 31) - 256 || (row0 & 63)) return hipErrorInvalidValue;
-  return launch_sell_mode<CSR_GS>(n_storage, 0, soff, scol, sval, u, f, u, 1.0, rowid, row0,
+  // the kernel's row bound is the END OF THIS COLOUR: a 256-thread workgroup must not run on
+  // into the storage rows of the next colour (they reference this colour's rows)
+  const int64_t end = row0 + count < n_storage ? row0 + count : n_storage;
+  return launch_sell_mode<CSR_GS>(end, 0, soff, scol, sval, u, f, u, 1.0, rowid, row0,
                                   count, nullptr, 0, st);
 }
 
@@ -1887,14 +1890,16 @@ static hipError_t launch_gs_lex_b(const LexDev& S, const double* b, double* u, i
   if (S.width <= 5) AMG_LEX(5);
   else if (S.width <= 7) AMG_LEX(7);
   else if (S.width <= 9) AMG_LEX(9);
-  else AMG_LEX(16);
+  else if (S.width <= 16) AMG_LEX(16);
+  else if (S.width <= 32) AMG_LEX(32);  // irregular coarse operators (strength-based coarsening, 3-D)
+  else AMG_LEX(64);
 #undef AMG_LEX
   return hipGetLastError();
 }
 hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, double omega,
                          hipStream_t st) {
   if (S.n_slots <= 0) return hipSuccess;
-  if (S.width > 16) return hipErrorInvalidValue;
+  if (S.width > 64) return hipErrorInvalidValue;
   switch (S.block) {
     case 64: return launch_gs_lex_b<64>(S, b, u, mode, omega, st);
     case 256: return launch_gs_lex_b<256>(S, b, u, mode, omega, st);

@@ -1171,10 +1171,12 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
                             const int32_t* const* Pc, const int32_t* const* Pr,
                             const double* const* Pv, const int32_t* const* Rc,
                             const int32_t* const* Rr, const double* const* Rv,
-                            const amg_hip_options* opts, amg_hip_solver** out) {
+                            const amg_hip_options* opts, amg_hip_solver** out,
+                            double rs_theta = -1.0, int64_t rs_min_coarse = 0) {
   if (!out) return fail(AMG_HIP_EINVAL, "out handle pointer is null");
   *out = nullptr;
   if (!colptr || !rowind || !val || !b) return fail(AMG_HIP_EINVAL, "null input array");
+  const bool rs = rs_theta >= 0.0;  // strength-based C/F coarsening: n_levels is an upper bound
   if (n <= 0) return fail(AMG_HIP_EINVAL, "`A` must have at least one degree of freedom");
   if (n_levels < 1) return fail(AMG_HIP_EINVAL, "`n_levels` must be at least 1");
   std::unique_ptr<amg_hip_solver> s(new amg_hip_solver);
@@ -1313,8 +1315,8 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
       // no schedule needed
     } else if (s->opt.smoother == AMG_HIP_SM_SPGS) {
       LexSchedule F, B;
-      std::string e = build_lex_schedule(L.A_csc, false, 16, &F);
-      if (e.empty()) e = build_lex_schedule(L.A_csc, true, 16, &B);
+      std::string e = build_lex_schedule(L.A_csc, false, 64, &F);
+      if (e.empty()) e = build_lex_schedule(L.A_csc, true, 64, &B);
       if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
       L.lex_fwd.reset(new LexOnDev);
       L.lex_bwd.reset(new LexOnDev);
@@ -1322,7 +1324,7 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
       HIP_TRY(upload_lex(B, L.lex_bwd.get()));
     } else if (s->opt.smoother == AMG_HIP_SM_REF_JACOBI || s->opt.smoother == AMG_HIP_SM_SOR) {
       LexSchedule F;  // these two address A by ROW (A.coeff(i,j), smoother.hpp:251,351)
-      std::string e = build_lex_schedule(A_r, false, 16, &F);
+      std::string e = build_lex_schedule(A_r, false, 64, &F);
       if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
       L.lex_fwd.reset(new LexOnDev);
       HIP_TRY(upload_lex(F, L.lex_fwd.get()));
@@ -1355,11 +1357,28 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
     if (l + 1 == n_levels) break;
     // ---- transfer operators for level l -> l+1 ----
     const int64_t n_h = L.n;
-    const int64_t n_H = coarse_dofs(n_h);  // multigrid.hpp:214
-    if (n_H < 1)
+    int64_t n_H = coarse_dofs(n_h);  // multigrid.hpp:214
+    if (rs) {
+      // host_setup.hpp: ruge_stueben_P.  The hierarchy ends where a level is small enough for
+      // the direct solve or no longer coarsens.
+      bool last = n_h <= rs_min_coarse;
+      if (!last) {
+        L.P_csc = ruge_stueben_P(A_r, rs_theta);
+        n_H = L.P_csc.n_outer;
+        last = n_H < 1 || n_H >= n_h;
+      }
+      if (last) {
+        L.P_csc = Sparse();
+        n_levels = l + 1;
+        s->lv.resize((size_t)n_levels);
+        break;
+      }
+      L.R_csc = transpose(L.P_csc);
+      L.linear = false;
+    } else if (n_H < 1) {
       return fail(AMG_HIP_EINVAL, "level " + std::to_string(l + 1) +
                                       " would have no degrees of freedom; reduce `n_levels`");
-    if (Pc) {
+    } else if (Pc) {
       L.P_csc = from_raw(n_H, n_h, Pc[l], Pr[l], Pv[l]);
       L.R_csc = from_raw(n_h, n_H, Rc[l], Rr[l], Rv[l]);
       std::string v = validate(L.P_csc, "P");
@@ -1864,6 +1883,16 @@ amg_hip_status amg_hip_create_custom(int64_t n, const int32_t* colptr, const int
     return fail(AMG_HIP_EINVAL, "custom transfer operator arrays are null");
   return build_solver(n, colptr, rowind, val, b, n_levels, P_colptr, P_rowind, P_val, R_colptr,
                       R_rowind, R_val, opts, out);
+}
+
+amg_hip_status amg_hip_create_rs(int64_t n, const int32_t* colptr, const int32_t* rowind,
+                                 const double* val, const double* b, int32_t max_levels,
+                                 double theta, int64_t min_coarse, const amg_hip_options* opts,
+                                 amg_hip_solver** out) {
+  if (!(theta >= 0.0 && theta <= 1.0)) return fail(AMG_HIP_EINVAL, "`theta` must be in [0, 1]");
+  if (min_coarse < 1) return fail(AMG_HIP_EINVAL, "`min_coarse` must be at least 1");
+  return build_solver(n, colptr, rowind, val, b, max_levels, nullptr, nullptr, nullptr, nullptr,
+                      nullptr, nullptr, opts, out, theta, min_coarse);
 }
 
 amg_hip_status amg_hip_create_poisson(int32_t dim, int64_t n, int32_t n_levels,
@@ -2660,14 +2689,14 @@ amg_hip_status amg_hip_smooth(int32_t kind, int64_t n, const int32_t* colptr,
   LexOnDev Lf, Lb;
   if (kind == AMG_HIP_SM_SPGS) {
     LexSchedule F, B;
-    std::string e = build_lex_schedule(A, false, 16, &F);
-    if (e.empty()) e = build_lex_schedule(A, true, 16, &B);
+    std::string e = build_lex_schedule(A, false, 64, &F);
+    if (e.empty()) e = build_lex_schedule(A, true, 64, &B);
     if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
     HIP_TRY(upload_lex(F, &Lf));
     HIP_TRY(upload_lex(B, &Lb));
   } else if (kind == AMG_HIP_SM_REF_JACOBI || kind == AMG_HIP_SM_SOR) {
     LexSchedule F;
-    std::string e = build_lex_schedule(Ar, false, 16, &F);
+    std::string e = build_lex_schedule(Ar, false, 64, &F);
     if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
     HIP_TRY(upload_lex(F, &Lf));
   } else if (kind == AMG_HIP_SM_JACOBI) {
@@ -2716,7 +2745,7 @@ amg_hip_status amg_hip_spgs_sweep(int32_t dir, int64_t n, const int32_t* colptr,
   std::string v = validate(A, "A");
   if (!v.empty()) return fail(AMG_HIP_EINVAL, v);
   LexSchedule S;
-  std::string e = build_lex_schedule(A, dir < 0, 16, &S);
+  std::string e = build_lex_schedule(A, dir < 0, 64, &S);
   if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
   LexOnDev L;
   HIP_TRY(upload_lex(S, &L));

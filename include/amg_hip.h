@@ -195,6 +195,19 @@ amg_hip_status amg_hip_create_custom(int64_t n, const int32_t* colptr,
                                      const amg_hip_options* opts,
                                      amg_hip_solver** out);
 
+/* Strength-based C/F coarsening (/root/reference README.md:104-109 names
+ * Ruge-Stueben as the alternative it did not build: NO reference counterpart, pinned to the
+ * oracle twin only).  Classical first-pass C/F splitting on the strength graph
+ * (threshold `theta`, typically 0.25) with direct interpolation, R = P^T, Galerkin R(AP) in
+ * the same summation order as the reference's chain; the hierarchy ends at `max_levels` or
+ * where a level has at most `min_coarse` rows or stops coarsening (amg_hip_n_levels tells).
+ * The same V-cycle (multigrid.hpp:263-305) then runs on it: general CSR transfer kernels,
+ * the smoother of `opts`, banded LDL^T of whatever width on the coarsest level.          */
+amg_hip_status amg_hip_create_rs(int64_t n, const int32_t* colptr, const int32_t* rowind,
+                                 const double* val, const double* b, int32_t max_levels,
+                                 double theta, int64_t min_coarse, const amg_hip_options* opts,
+                                 amg_hip_solver** out);
+
 /* The same constructor for the reference's own model problem, A = Grid::laplacian(n) and
  * b = Grid::rhs(n) (grid.hpp:88-98,108-140; dim = 3: the 7-point analogue), with the built-in
  * LinearInterpolator -- SETUP ON THE DEVICE END TO END: the

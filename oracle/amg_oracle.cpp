@@ -540,7 +540,10 @@ struct Multigrid {
 size_t n_H_dofs_from_n_h_dofs(size_t h_dofs) { return (h_dofs + 1) / 2 - 1; }
 
 // multigrid.hpp:181-244 with LinearInterpolator (interpolator.hpp:106-141).
-Multigrid* mg_create(const Csc& A0, const double* b, size_t n_levels) {
+// custom_P: transfer operators handed over (a user InterpolatorBase, interpolator.hpp:43-44,
+// or the strength-based coarsening twin in oracle.py); else LinearInterpolator's.
+Multigrid* mg_create(const Csc& A0, const double* b, size_t n_levels,
+                     const std::vector<Csc>* custom_P = nullptr) {
   Multigrid* M = new Multigrid;
   M->n_levels = n_levels;
   M->A.resize(n_levels);
@@ -559,8 +562,8 @@ Multigrid* mg_create(const Csc& A0, const double* b, size_t n_levels) {
   residual(A0, M->u[0].data(), M->f[0].data(), M->r[0].data());
   for (size_t l = 1; l < n_levels; ++l) {
     const size_t n_h = (size_t)M->A[l - 1].rows;
-    const size_t n_H = n_H_dofs_from_n_h_dofs(n_h);
-    M->P[l - 1] = make_P(n_h, n_H);
+    const size_t n_H = custom_P ? (size_t)(*custom_P)[l - 1].cols : n_H_dofs_from_n_h_dofs(n_h);
+    M->P[l - 1] = custom_P ? (*custom_P)[l - 1] : make_P(n_h, n_H);
     M->R[l - 1] = transpose(M->P[l - 1]);
     Csc AP = spgemm(M->A[l - 1], M->P[l - 1]);
     M->A[l] = spgemm(M->R[l - 1], AP);
@@ -747,6 +750,30 @@ void* orc_mg_create(int64_t n, const int32_t* colptr, const int32_t* rowind,
                     const double* val, const double* b, uint64_t n_levels) {
   if (n_levels == 0) return nullptr;
   return mg_create(csc_from_raw(n, n, colptr, rowind, val), b, n_levels);
+}
+// P_l (n_l x n_{l+1}) for l = 0 .. n_levels-2 as CSC triples; R_l = P_l^T
+void* orc_mg_create_custom(int64_t n, const int32_t* colptr, const int32_t* rowind,
+                           const double* val, const double* b, uint64_t n_levels,
+                           const int64_t* P_cols, const int32_t* const* P_colptr,
+                           const int32_t* const* P_rowind, const double* const* P_val) {
+  if (n_levels == 0) return nullptr;
+  std::vector<Csc> Ps;
+  int64_t rows = n;
+  for (uint64_t l = 0; l + 1 < n_levels; ++l) {
+    Ps.push_back(csc_from_raw(rows, P_cols[l], P_colptr[l], P_rowind[l], P_val[l]));
+    rows = P_cols[l];
+  }
+  return mg_create(csc_from_raw(n, n, colptr, rowind, val), b, n_levels, &Ps);
+}
+// C = A B in Eigen's conservative order (spgemm above); arrays may be null: returns nnz(C)
+int64_t orc_spgemm(int64_t a_rows, int64_t a_cols, const int32_t* a_colptr, const int32_t* a_rowind,
+                   const double* a_val, int64_t b_cols, const int32_t* b_colptr,
+                   const int32_t* b_rowind, const double* b_val, int32_t* c_colptr,
+                   int32_t* c_rowind, double* c_val) {
+  Csc Cm = spgemm(csc_from_raw(a_rows, a_cols, a_colptr, a_rowind, a_val),
+                  csc_from_raw(a_cols, b_cols, b_colptr, b_rowind, b_val));
+  if (c_colptr && c_rowind && c_val) csc_to_raw(Cm, c_colptr, c_rowind, c_val);
+  return Cm.nnz();
 }
 void orc_mg_destroy(void* h) { delete (Multigrid*)h; }
 void orc_mg_set_smoother(void* h, int kind, uint64_t iters, double omega) {

@@ -69,6 +69,13 @@ def _bind(L):
     L.orc_band_solve.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
     L.orc_mg_create.restype = C.c_void_p
     L.orc_mg_create.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_uint64]
+    L.orc_mg_create_custom.restype = C.c_void_p
+    L.orc_mg_create_custom.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_uint64,
+                                       C.POINTER(C.c_int64), C.POINTER(_i32p), C.POINTER(_i32p),
+                                       C.POINTER(_f64p)]
+    L.orc_spgemm.restype = C.c_int64
+    L.orc_spgemm.argtypes = [C.c_int64, C.c_int64, _i32p, _i32p, _f64p, C.c_int64, _i32p, _i32p, _f64p,
+                             _i32p, _i32p, _f64p]
     L.orc_mg_destroy.restype = None
     L.orc_mg_destroy.argtypes = [C.c_void_p]
     L.orc_mg_set_smoother.restype = None
@@ -254,14 +261,156 @@ def band_solve(A, f):
     return x, int(w)
 
 
+def spgemm(A, B):
+    """C = A B, Eigen's conservative sparse product (what multigrid.hpp:222 runs)."""
+    nnz = lib().orc_spgemm(A.rows, A.cols, _p32(A.colptr), _p32(A.rowind), _p64(A.val), B.cols,
+                           _p32(B.colptr), _p32(B.rowind), _p64(B.val), None, None, None)
+    cp, ri, v = np.empty(B.cols + 1, np.int32), np.empty(nnz, np.int32), np.empty(nnz, np.float64)
+    lib().orc_spgemm(A.rows, A.cols, _p32(A.colptr), _p32(A.rowind), _p64(A.val), B.cols,
+                     _p32(B.colptr), _p32(B.rowind), _p64(B.val), _p32(cp), _p32(ri), _p64(v))
+    return CSC(A.rows, B.cols, cp, ri, v)
+
+
+def ruge_stueben_P(A, theta=0.25):
+    """Strength-based C/F splitting + direct interpolation: the twin of the product's
+    host_setup.cpp: ruge_stueben_P (NO counterpart in the reference, whose README.md:104-109
+    only names the method).  Written from the textbook description (Briggs, Henson,
+    McCormick: A Multigrid Tutorial, ch. 8; Ruge & Stueben 1987), plain Python on purpose:
+      s_ij = -sign(a_ii) a_ij;  i depends strongly on j  <=>  s_ij > 0 and s_ij >= theta max_k s_ik
+      first pass: the undecided point with the most strong dependants (ties: lowest index)
+        becomes C, its undecided dependants F, the undecided points those depend on gain one,
+        the undecided points the new C point depends on lose one; no strong coupling -> F
+      F row i over C_i = strong C neighbours (ascending column sums):
+        w_ij = -(sum_{s_ik>0} a_ik / sum_{k in C_i} a_ik) a_ij / (a_ii + sum_{s_ik<0} a_ik)
+    Returns (P as CSC n x n_c, is_c)."""
+    import heapq
+    R = A.transpose()           # CSC(A^T) = rows of A
+    n = A.rows
+    ptr, idx, val = R.colptr, R.rowind, R.val
+    S = [[] for _ in range(n)]
+    ST = [[] for _ in range(n)]
+    sgn = np.ones(n)
+    for i in range(n):
+        d = 0.0
+        for p in range(ptr[i], ptr[i + 1]):
+            if idx[p] == i:
+                d = val[p]
+        sgn[i] = -1.0 if d < 0.0 else 1.0
+        mx = 0.0
+        for p in range(ptr[i], ptr[i + 1]):
+            if idx[p] != i:
+                mx = max(mx, -sgn[i] * val[p])
+        if mx > 0.0:
+            thr = theta * mx
+            for p in range(ptr[i], ptr[i + 1]):
+                sij = -sgn[i] * val[p]
+                if idx[p] != i and sij > 0.0 and sij >= thr:
+                    S[i].append(int(idx[p]))
+    for i in range(n):
+        for j in S[i]:
+            ST[j].append(i)
+    U, Cp, Fp = 0, 1, 2
+    st = [U] * n
+    lam = [len(ST[i]) for i in range(n)]
+    heap = []
+    for i in range(n):
+        if not S[i]:
+            st[i] = Fp
+        else:
+            heap.append((-lam[i], i))
+    heapq.heapify(heap)
+    while heap:
+        ml, i = heapq.heappop(heap)
+        if st[i] != U or lam[i] != -ml:
+            continue
+        st[i] = Cp
+        for j in ST[i]:
+            if st[j] != U:
+                continue
+            st[j] = Fp
+            for k in S[j]:
+                if st[k] == U:
+                    lam[k] += 1
+                    heapq.heappush(heap, (-lam[k], k))
+        for j in S[i]:
+            if st[j] == U:
+                lam[j] -= 1
+                heapq.heappush(heap, (-lam[j], j))
+    cidx = [-1] * n
+    nc = 0
+    for i in range(n):
+        if st[i] == Cp:
+            cidx[i] = nc
+            nc += 1
+    rows_ptr, rows_idx, rows_val = [0], [], []
+    for i in range(n):
+        if st[i] == Cp:
+            rows_idx.append(cidx[i])
+            rows_val.append(1.0)
+        else:
+            num = den = dg = 0.0
+            a = {}
+            for p in range(ptr[i], ptr[i + 1]):
+                if idx[p] == i:
+                    dg = float(val[p])
+            for p in range(ptr[i], ptr[i + 1]):
+                j = int(idx[p])
+                if j == i:
+                    continue
+                a[j] = float(val[p])
+                sij = -sgn[i] * val[p]
+                if sij > 0.0:
+                    num += float(val[p])
+                elif sij < 0.0:
+                    dg += float(val[p])
+            for j in S[i]:
+                if st[j] == Cp:
+                    den += a[j]
+            if den != 0.0 and dg != 0.0:
+                alpha = num / den
+                for j in S[i]:
+                    if st[j] == Cp:
+                        rows_idx.append(cidx[j])
+                        rows_val.append(-alpha * a[j] / dg)
+        rows_ptr.append(len(rows_idx))
+    Pr = CSC(nc, n, rows_ptr, rows_idx, rows_val)      # CSC(P^T) = rows of P
+    return Pr.transpose(), np.array([s == Cp for s in st])
+
+
+def ruge_stueben_hierarchy(A, max_levels=25, theta=0.25, min_coarse=500):
+    """P_l for amg_hip_create_rs's rule: stop at max_levels, at a level of at most min_coarse
+    rows, or where a level no longer coarsens; A_{l+1} = R (A P) with R = P^T (multigrid.hpp:219-223)."""
+    Ps = []
+    Al = A
+    while len(Ps) + 1 < max_levels and Al.rows > min_coarse:
+        P, _ = ruge_stueben_P(Al, theta)
+        if P.cols < 1 or P.cols >= Al.rows:
+            break
+        Ps.append(P)
+        Al = spgemm(P.transpose(), spgemm(Al, P))
+    return Ps
+
+
 class Multigrid:
     """Restatement of AMG::Multigrid<double> (multigrid.hpp) with
     LinearInterpolator and a selectable smoother (default SparseGaussSeidel())."""
 
-    def __init__(self, A, b, n_levels, smoother=SM_SPGS, smoother_iters=1, omega=1.0, library=None):
+    def __init__(self, A, b, n_levels, smoother=SM_SPGS, smoother_iters=1, omega=1.0, library=None,
+                 transfers=None):
+        """transfers: P_l (CSC objects, n_l x n_{l+1}) of a custom interpolator; R_l = P_l^T."""
         self._L = library or lib()
-        self._h = self._L.orc_mg_create(A.rows, _p32(A.colptr), _p32(A.rowind),
-                                      _p64(A.val), _p64(np.ascontiguousarray(b)), n_levels)
+        if transfers is None:
+            self._h = self._L.orc_mg_create(A.rows, _p32(A.colptr), _p32(A.rowind),
+                                            _p64(A.val), _p64(np.ascontiguousarray(b)), n_levels)
+        else:
+            assert len(transfers) == n_levels - 1
+            k = max(len(transfers), 1)
+            cols = (C.c_int64 * k)(*[P.cols for P in transfers])
+            cp = (_i32p * k)(*[_p32(P.colptr) for P in transfers])
+            ri = (_i32p * k)(*[_p32(P.rowind) for P in transfers])
+            vv = (_f64p * k)(*[_p64(P.val) for P in transfers])
+            self._h = self._L.orc_mg_create_custom(A.rows, _p32(A.colptr), _p32(A.rowind), _p64(A.val),
+                                                   _p64(np.ascontiguousarray(b)), n_levels, cols, cp, ri, vv)
         if not self._h:
             raise ValueError("orc_mg_create failed")
         self.n_levels = n_levels
