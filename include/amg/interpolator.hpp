@@ -6,6 +6,7 @@
 // the operators of LinearInterpolator are recognised and replaced by matrix-free kernels.
 #pragma once
 #include <array>
+#include <stdexcept>
 #include <vector>
 
 #include <amg/eigen_lite.hpp>
@@ -69,6 +70,28 @@ class LinearInterpolator : public InterpolatorBase<EleType> {
     Eigen::SparseMatrix<EleType> R = P.transpose();
     this->set_level_to_P(level, P);
     this->set_level_to_R(level, R);
+  }
+};
+
+// Strength-based C/F coarsening with direct interpolation -- the alternative the reference's
+// README.md:104-109 names and does not build (NO reference counterpart).  Its operators depend
+// on the level MATRIX, which make_operators(n_h, n_H, level) is never told, so AMG::Multigrid
+// recognises the class and lets the library build the hierarchy (amg_hip_create_rs): `n_levels`
+// is then an upper bound, Multigrid::get_n_levels() tells how many were built, and get_P /
+// get_R hold the operators afterwards.
+template <class EleType>
+class RugeStuebenInterpolator : public InterpolatorBase<EleType> {
+  EleType theta_;
+  size_t min_coarse_;
+
+ public:
+  explicit RugeStuebenInterpolator(size_t max_levels, EleType theta = 0.25, size_t min_coarse = 500)
+      : InterpolatorBase<EleType>(max_levels), theta_(theta), min_coarse_(min_coarse) {}
+  EleType theta() const { return theta_; }
+  size_t min_coarse() const { return min_coarse_; }
+  void make_operators(size_t, size_t, size_t) override {
+    throw std::logic_error("RugeStuebenInterpolator: the operators depend on the level matrix; "
+                           "AMG::Multigrid builds them");
   }
 };
 

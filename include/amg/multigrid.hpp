@@ -42,6 +42,20 @@ class Multigrid {
 
   size_t n_H_dofs_from_n_h_dofs(size_t h_dofs) { return (h_dofs + 1) / 2 - 1; }  // :127-130
 
+  void fetch_level_matrices() {
+    level_to_coefficient_matrix.resize(n_levels);
+    for (size_t l = 0; l < n_levels; ++l) {
+      const size_t n = level_to_n_dofs[l];
+      const int64_t nnz = amg_hip_get_level_nnz(handle, (int32_t)l);
+      std::vector<int32_t> cp(n + 1), ri((size_t)nnz);
+      std::vector<double> v((size_t)nnz);
+      detail::check(amg_hip_get_level_matrix(handle, (int32_t)l, cp.data(), ri.data(), v.data()));
+      level_to_coefficient_matrix[l] = detail::make_sparse<EleType>(n, n, cp.data(), ri.data(), v.data());
+    }
+    level_to_soln.resize(n_levels);
+    level_to_rhs.resize(n_levels);
+  }
+
   const Vector& fetch(std::vector<Vector>& cache, size_t level, int which) const {
     Vector& v = cache[level];
     if ((size_t)v.size() != level_to_n_dofs[level]) v.resize(level_to_n_dofs[level]);
@@ -105,6 +119,38 @@ class Multigrid {
       opt.smoother_iters = 0;
     }
 
+    if (auto* rs = dynamic_cast<RugeStuebenInterpolator<EleType>*>(interpolator)) {
+      // strength-based coarsening: the library derives level sizes and operators from A
+      const Sparse A0 = detail::compressed(A);
+      detail::check(amg_hip_create_rs(A0.rows(), A0.outerIndexPtr(), A0.innerIndexPtr(), A0.valuePtr(),
+                                      b.data(), (int32_t)n_levels, (double)rs->theta(),
+                                      (int64_t)rs->min_coarse(), &opt, &handle));
+      try {
+        n_levels = (size_t)amg_hip_n_levels(handle);
+        level_to_n_dofs.resize(n_levels);
+        for (size_t l = 0; l < n_levels; ++l)
+          level_to_n_dofs[l] = (size_t)amg_hip_get_n_dofs(handle, (int32_t)l);
+        for (size_t l = 0; l + 1 < n_levels; ++l)
+          for (int which = 0; which < 2; ++which) {  // 0 = P (n_l x n_{l+1}), 1 = R
+            const int64_t nnz = amg_hip_get_transfer_nnz(handle, (int32_t)l, which);
+            const size_t rows = which == 0 ? level_to_n_dofs[l] : level_to_n_dofs[l + 1];
+            const size_t cols = which == 0 ? level_to_n_dofs[l + 1] : level_to_n_dofs[l];
+            std::vector<int32_t> cp(cols + 1), ri((size_t)nnz);
+            std::vector<double> v((size_t)nnz);
+            detail::check(amg_hip_get_transfer(handle, (int32_t)l, which, cp.data(), ri.data(), v.data()));
+            Sparse M = detail::make_sparse<EleType>(rows, cols, cp.data(), ri.data(), v.data());
+            if (which == 0) interpolator->set_level_to_P(l, M);
+            else interpolator->set_level_to_R(l, M);
+          }
+        fetch_level_matrices();
+      } catch (...) {
+        amg_hip_destroy(handle);
+        handle = nullptr;
+        throw;
+      }
+      return;
+    }
+
     // level sizes + transfer operators: make_operators runs on the host and
     // overwrites levels 0..L-2 of the caller's interpolator, as in the
     // reference (:211-216); P/R go to the device as CSC triples.
@@ -136,17 +182,7 @@ class Multigrid {
     // host copies of the level matrices (get_coefficient_matrix returns const&); the
     // destructor does not run when a constructor throws, so the handle is released here
     try {
-      level_to_coefficient_matrix.resize(n_levels);
-      for (size_t l = 0; l < n_levels; ++l) {
-        const size_t n = level_to_n_dofs[l];
-        const int64_t nnz = amg_hip_get_level_nnz(handle, (int32_t)l);
-        std::vector<int32_t> cp(n + 1), ri((size_t)nnz);
-        std::vector<double> v((size_t)nnz);
-        detail::check(amg_hip_get_level_matrix(handle, (int32_t)l, cp.data(), ri.data(), v.data()));
-        level_to_coefficient_matrix[l] = detail::make_sparse<EleType>(n, n, cp.data(), ri.data(), v.data());
-      }
-      level_to_soln.resize(n_levels);
-      level_to_rhs.resize(n_levels);
+      fetch_level_matrices();
     } catch (...) {
       amg_hip_destroy(handle);
       handle = nullptr;
@@ -196,6 +232,7 @@ class Multigrid {
   const Vector& get_soln(size_t level) const { return fetch(level_to_soln, level, 0); }
   const Vector& get_rhs(size_t level) const { return fetch(level_to_rhs, level, 1); }
   const size_t get_n_dofs(size_t level) const { return level_to_n_dofs[level]; }
+  size_t get_n_levels() const { return n_levels; }  // extension: RugeStuebenInterpolator decides
   const EleType get_tolerance() const { return tolerance; }
   void display_error_on() { display_error = true; }
   void display_error_off() { display_error = true; }  // sic: reference multigrid.hpp:361-364

@@ -186,6 +186,26 @@ int main() {
     CHECK_THROWS_AS(bad_pcg(), std::invalid_argument);
   }
 
+  // strength-based C/F coarsening (reference README.md:104-109: considered, not built): the
+  // same Multigrid object on a Ruge-Stueben hierarchy needs far fewer cycles than the 35 above
+  {
+    AMG::RugeStuebenInterpolator<double> rs(12, 0.25, 20);
+    AMG::SparseGaussSeidel<double> sm;
+    AMG::Multigrid<double> amg_rs(&rs, &sm, amg_A, amg_b, 12, 1e-9, 1, 100);
+    CHECK(amg_rs.get_n_levels() >= 3 && amg_rs.get_n_levels() <= 12);
+    CHECK(amg_rs.get_n_dofs(1) < amg_rs.get_n_dofs(0) && amg_rs.get_n_dofs(1) >= amg_rs.get_n_dofs(0) / 2 - 1);
+    CHECK((size_t)rs.get_P(0).rows() == amg_rs.get_n_dofs(0) && (size_t)rs.get_P(0).cols() == amg_rs.get_n_dofs(1));
+    CHECK((size_t)amg_rs.get_coefficient_matrix(1).rows() == amg_rs.get_n_dofs(1));
+    size_t cycles = 0;
+    double err = AMG::rss(amg_A, amg_rs.get_soln(0), amg_b);
+    while (err > 1e-9 && cycles < 35) { amg_rs.vcycle(); ++cycles; err = AMG::rss(amg_A, amg_rs.get_soln(0), amg_b); }
+    CHECK(err <= 1e-9);
+    CHECK(cycles <= 12);
+    CHECK(amg_rs.get_soln(0).isApprox(amg_u, 1e-6));
+    auto direct = [&]() { rs.make_operators(10, 4, 0); };
+    CHECK_THROWS_AS(direct(), std::logic_error);
+  }
+
   std::cout << (n_failed ? "SOME TESTS FAILED" : "All tests passed") << " (" << n_checks
             << " assertions)" << std::endl;
   return n_failed ? 1 : 0;

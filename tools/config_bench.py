@@ -42,7 +42,39 @@ def run(dim, n, L, sm, cycles=10, warm=6, **extra):
     mg.close()
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "all":
+def run_rs(n, sm, cycles=10, theta=0.25, min_coarse=500, dim=2):
+    """Strength-based C/F hierarchy (amg_hip_create_rs) on the same problem; reports the cycles
+    and time to reduce the residual norm by 1e-8 next to the rate."""
+    cp, ri, v = amg.laplacian(n, dim)
+    b = amg.rhs(n, dim)
+    t0 = time.time()
+    mg = amg.Multigrid.ruge_stueben(cp, ri, v, b, 25, theta, min_coarse, **KW[sm])
+    mg.sync()
+    setup = time.time() - t0
+    L = mg.n_levels
+    r0 = mg.rss()
+    t1 = time.perf_counter()
+    mg.vcycle(cycles)
+    mg.sync()
+    dt = (time.perf_counter() - t1) / cycles
+    r1 = mg.rss()
+    fac = (r1 / r0) ** (0.5 / cycles)
+    import math
+    need = math.ceil(math.log(1e-8) / math.log(fac)) if fac < 1 else float("inf")
+    sizes = [mg.get_n_dofs(l) for l in range(L)]
+    print(f"RS dim={dim} n={n} dofs={n**dim} levels={L} sizes={sizes[:4]}..{sizes[-1]} smoother={sm}: setup {setup:.2f}s, "
+          f"{dt*1e3:.3f} ms/V-cycle = {1/dt:.1f} V-cycles/s, coarsest half-bw {mg.coarse_halfbw()}, "
+          f"||r|| factor per cycle {fac:.4f}: 1e-8 in {need} cycles = {need*dt*1e3:.1f} ms", flush=True)
+    mg.close()
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "rs":
+    for n in (512, 1024, 2048):
+        run_rs(n, "multicolor")
+        run_rs(n, "jacobi")
+    run_rs(1024, "spgs", 5)
+    run_rs(64, "jacobi", 10, dim=3)
+elif len(sys.argv) > 1 and sys.argv[1] == "all":
     run(2, 128, 3, "spgs", 20)                         # BASELINE config 1 (exact kernel: small)
     run(2, 1024, 6, "spgs", 5)                         # config 2, the reference's default smoother
     run(2, 1024, 6, "spgs", 5, exact_gs=True, exact_coarse_solve=True)   # ... parity mode
