@@ -120,6 +120,7 @@ _SIGS = {
     "amg_hip_coarse_solve_kind": (C.c_int32, [C.c_void_p]),
     "amg_hip_fine_sweep_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _i32p, _f64p]),
     "amg_hip_set_patch_min_rows": (None, [C.c_int64]),
+    "amg_hip_set_band_chain": (None, [C.c_int32]),
     "amg_hip_create_rs": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_int32, C.c_double, C.c_int64,
                                     C.POINTER(Options), C.POINTER(C.c_void_p)]),
     "amg_hip_slab_plan": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(SlabInfo)]),
@@ -263,6 +264,10 @@ def slab_plan(lines, rank, world, levels):
     info = SlabInfo()
     _chk(lib().amg_hip_slab_plan(int(lines), int(rank), int(world), int(levels), C.byref(info)))
     return info
+
+
+def set_band_chain(on):
+    lib().amg_hip_set_band_chain(int(bool(on)))
 
 
 def set_patch_min_rows(rows):
@@ -527,7 +532,8 @@ class Multigrid:
 
     def coarse_solve_kind(self):
         return {0: "band (one wave, sequential, bit-exact)", 1: "spike (partitioned, parallel)",
-                2: "band-wide (blocked sequential, any half-bandwidth, bit-exact)"}[
+                2: "band-wide (blocked sequential, any half-bandwidth, bit-exact)",
+                3: "band-chain (LDS-resident scalar recurrence, half-bandwidth <= 3, bit-exact)"}[
                     int(lib().amg_hip_coarse_solve_kind(self._h))]
 
     def level_op(self, level, op):

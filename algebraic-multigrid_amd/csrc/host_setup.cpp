@@ -537,6 +537,23 @@ std::string band_schedule(const BandFactor& F, BandSchedule* S) {
   return "";
 }
 
+void band_chain_schedule(const BandFactor& F, BandChain* S) {
+  const int64_t n = F.n, w = F.w;
+  S->n = n;
+  S->w = w;
+  S->d = F.d;
+  S->cf.assign((size_t)(n * w), 0.0);
+  S->cb.assign((size_t)(n * w), 0.0);
+  auto L = [&](int64_t i, int64_t j) -> double { return F.lcol[j * w + (i - j - 1)]; };  // i > j
+  for (int64_t s = 0; s < n; ++s)
+    for (int64_t t = 0; t < w; ++t) {
+      const int64_t k = s - w + t;            // forward: row s, column k
+      if (k >= 0) S->cf[s * w + t] = L(s, k);
+      const int64_t i = n - 1 - s, r = i + w - t;  // backward: unknown i, row r > i
+      if (r < n) S->cb[s * w + t] = L(r, i);
+    }
+}
+
 std::string band_wide_schedule(const BandFactor& F, size_t max_bytes, BandWide* S) {
   const int64_t n = F.n, w = F.w;
   if (w + 64 > 8192)

@@ -126,6 +126,16 @@ struct BandSchedule {
 // fails when w > 63
 std::string band_schedule(const BandFactor& F, BandSchedule* out);
 
+// Device layout for the narrow-band LDS kernel (K-BandChain, w <= 3): per step s the w
+// operands of the recurrence, farthest column first.
+//   cf[s*w + t] = L[s, s-w+t]           (0 when the column is negative)
+//   cb[s*w + t] = L[i+w-t, i], i = n-1-s (0 when the row is past the end)
+struct BandChain {
+  int64_t n = 0, w = 0;
+  std::vector<double> cf, cb, d;
+};
+void band_chain_schedule(const BandFactor& F, BandChain* out);
+
 // Device layout for the general-bandwidth kernel (K-BandWide, w > 63): rows in blocks of
 // 64.  Per block b a panel of (w + 64) x 64 doubles, [t][lane]:
 //   t < w : L[i, i-w+t] for row i = 64 b + lane when that column lies in an EARLIER block

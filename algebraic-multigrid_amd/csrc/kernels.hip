@@ -2627,6 +2627,110 @@ __global__ __launch_bounds__(64) void band_solve_kernel(
   band_pass<M, false>(n, lane, sched_b, y, x);          // L^T x = z
 }
 
+// ------------------------------------------------------------- K-BandChain ----
+// The same substitution for the NARROW coarsest operators of deep hierarchies (half-bandwidth
+// w <= 3, a few hundred rows: 511 rows / w = 2 on the 16-level 4096^2 hierarchy), where the
+// broadcast-and-update scheme above spends ~48 ns per step on lane traffic.  Here the whole
+// problem sits in LDS and every lane walks the recurrence redundantly as plain scalar code:
+//   y_s = rhs_s - sum_t c[s][t] * y_{s-w+t},  t = 0 .. w-1  (ascending k, farthest first:
+// the order in which K-Band's updates reach a row, so the bits are the same),
+// with the operands of the next 8 steps read ahead of the dependent multiply / subtract chain
+// (one multiply and one subtract per step on the critical path).  The backward pass runs the
+// same code on the mirrored system (step s = row n-1-s; host_setup.cpp: band_chain_schedule).
+constexpr int CHAIN_CH = 8;  // steps per read-ahead chunk
+__host__ __device__ inline int band_chain_pad(int n) { return (n + 2 * CHAIN_CH - 1) / (2 * CHAIN_CH) * (2 * CHAIN_CH) + 2 * CHAIN_CH; }
+template <int W>
+struct ChainChunk {
+  double o[CHAIN_CH][W], r[CHAIN_CH];
+};
+// ops / v are padded to band_chain_pad(n) steps (zero operands): no bounds checks on reads
+template <int W>
+__device__ __forceinline__ void band_chain_fetch(ChainChunk<W>& c, const double* op, const double* rv) {
+#pragma unroll
+  for (int i = 0; i < CHAIN_CH; ++i) {
+#pragma unroll
+    for (int t = 0; t < W; ++t) c.o[i][t] = op[i * W + t];
+    c.r[i] = rv[i];
+  }
+}
+template <int W>
+__device__ __forceinline__ void band_chain_steps(const ChainChunk<W>& c, double (&prev)[W], int lane,
+                                                 int left, double* out) {
+  double mine = 0.0;
+#pragma unroll
+  for (int i = 0; i < CHAIN_CH; ++i) {
+    double acc = c.r[i];
+#pragma unroll
+    for (int t = 0; t < W; ++t) acc -= c.o[i][t] * prev[t];
+#pragma unroll
+    for (int t = 0; t + 1 < W; ++t) prev[t] = prev[t + 1];
+    prev[W - 1] = acc;
+    mine = lane == i ? acc : mine;
+  }
+  if (lane < CHAIN_CH && lane < left) out[lane] = mine;  // one wave: LDS keeps program order
+}
+template <int W>
+__device__ __forceinline__ void band_chain_pass(int n, const double* ops, double* v) {
+  const int lane = threadIdx.x;
+  double prev[W];
+#pragma unroll
+  for (int t = 0; t < W; ++t) prev[t] = 0.0;
+  ChainChunk<W> A, B;
+  band_chain_fetch<W>(A, ops, v);
+  for (int s0 = 0; s0 < n; s0 += 2 * CHAIN_CH) {
+    const double* op = ops + s0 * W;
+    double* rv = v + s0;
+    band_chain_fetch<W>(B, op + CHAIN_CH * W, rv + CHAIN_CH);
+    band_chain_steps<W>(A, prev, lane, n - s0, rv);
+    band_chain_fetch<W>(A, op + 2 * CHAIN_CH * W, rv + 2 * CHAIN_CH);
+    band_chain_steps<W>(B, prev, lane, n - s0 - CHAIN_CH, rv + CHAIN_CH);
+  }
+}
+template <int W>
+__global__ __launch_bounds__(64) void band_chain_kernel(
+    int n, const double* __restrict__ cf, const double* __restrict__ cb,
+    const double* __restrict__ dg, const double* __restrict__ f, double* __restrict__ x) {
+  extern __shared__ double chain_lds[];
+  const int np = band_chain_pad(n);
+  double* ops = chain_lds;           // np x W
+  double* v = chain_lds + np * W;    // np: right-hand side in step order, then the result
+  const int lane = threadIdx.x;
+  for (int k = lane; k < np * W; k += 64) ops[k] = k < n * W ? cf[k] : 0.0;
+  for (int s = lane; s < np; s += 64) v[s] = s < n ? f[s] : 0.0;
+  lds_barrier();
+  band_chain_pass<W>(n, ops, v);                 // L y = f
+  lds_barrier();
+  double z[32];                                  // n <= 2048: z = y / D, mirrored
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int s = lane + 64 * q;
+    z[q] = s < n ? v[n - 1 - s] / dg[n - 1 - s] : 0.0;
+  }
+  for (int k = lane; k < n * W; k += 64) ops[k] = cb[k];
+  lds_barrier();
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int s = lane + 64 * q;
+    if (s < n) v[s] = z[q];
+  }
+  lds_barrier();
+  band_chain_pass<W>(n, ops, v);                 // L^T x = z, step s = row n-1-s
+  lds_barrier();
+  for (int s = lane; s < n; s += 64) x[n - 1 - s] = v[s];
+}
+bool band_chain_ok(int64_t n, int64_t w) { return w >= 1 && w <= 3 && n >= 1 && n <= 2048; }
+hipError_t launch_band_chain(int64_t n, int w, const double* cf, const double* cb, const double* dg,
+                             const double* f, double* x, hipStream_t st) {
+  if (!band_chain_ok(n, w)) return hipErrorInvalidValue;
+  const size_t lds = sizeof(double) * (size_t)band_chain_pad((int)n) * (size_t)(w + 1);
+  switch (w) {
+    case 1: hipLaunchKernelGGL(band_chain_kernel<1>, dim3(1), dim3(64), lds, st, (int)n, cf, cb, dg, f, x); break;
+    case 2: hipLaunchKernelGGL(band_chain_kernel<2>, dim3(1), dim3(64), lds, st, (int)n, cf, cb, dg, f, x); break;
+    default: hipLaunchKernelGGL(band_chain_kernel<3>, dim3(1), dim3(64), lds, st, (int)n, cf, cb, dg, f, x); break;
+  }
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------- K-BandWide -----
 // The same LDL^T substitution for ANY half-bandwidth w (the reference's SimplicialLDLT
 // factors whatever coarsest matrix it is given, multigrid.hpp:240-243): rows in blocks of

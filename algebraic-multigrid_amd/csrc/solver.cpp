@@ -575,7 +575,8 @@ hipError_t upload_spike(const SpikeFactor& S, SpikeOnDev* D) {
 //   BAND  one-wave substitution, half-bandwidth <= 63, bit-exact against the oracle
 //   SPIKE partitioned (parallel) form of the same factor, <= 63, agrees to ~1e-14
 //   WIDE  blocked one-wave substitution for any half-bandwidth, bit-exact
-enum CoarseKind { COARSE_BAND = 0, COARSE_SPIKE = 1, COARSE_WIDE = 2 };
+enum CoarseKind { COARSE_BAND = 0, COARSE_SPIKE = 1, COARSE_WIDE = 2, COARSE_CHAIN = 3 };
+int g_no_band_chain = 0;  // amg_hip_set_band_chain
 struct CoarseOnDev {
   int kind = COARSE_BAND;
   int64_t n = 0, w = 0;
@@ -618,6 +619,15 @@ amg_hip_status upload_coarse(const Sparse& A, int want_fast, CoarseOnDev* C) {
       return AMG_HIP_OK;
     }
   }
+  if (band_chain_ok(F.n, F.w) && !g_no_band_chain) {
+    BandChain S;
+    band_chain_schedule(F, &S);
+    C->kind = COARSE_CHAIN;
+    HIP_TRY(upload(C->sf, S.cf.data(), S.cf.size()));
+    HIP_TRY(upload(C->sb, S.cb.data(), S.cb.size()));
+    HIP_TRY(upload(C->d, S.d.data(), S.d.size()));
+    return AMG_HIP_OK;
+  }
   BandSchedule S;
   e = band_schedule(F, &S);
   if (!e.empty()) return fail(AMG_HIP_EUNSUPPORTED, e);
@@ -641,6 +651,9 @@ hipError_t launch_coarse(const CoarseOnDev& C, const double* f, double* y, doubl
     case COARSE_WIDE:
       return launch_band_wide(C.n, C.w, C.sf.as<double>(), C.sb.as<double>(), C.d.as<double>(), f,
                               y, x, st);
+    case COARSE_CHAIN:
+      return launch_band_chain(C.n, (int)C.w, C.sf.as<double>(), C.sb.as<double>(), C.d.as<double>(),
+                               f, x, st);
     default:
       return launch_band_solve(C.n, C.m, C.sf.as<double>(), C.sb.as<double>(), C.d.as<double>(),
                                f, y, x, st);
@@ -1853,6 +1866,7 @@ void amg_hip_set_nontemporal(int32_t on) { g_nontemporal = on ? 1 : 0; }
 void amg_hip_set_xcd_mapping(int32_t on) { set_xcd_mapping(on); }
 void amg_hip_set_row_types(int32_t on) { g_row_types = on ? 1 : 0; }
 void amg_hip_set_dict_rows(int32_t rows_per_lane) { set_dict_rows_per_lane(rows_per_lane); }
+void amg_hip_set_band_chain(int32_t on) { g_no_band_chain = on ? 0 : 1; }
 void amg_hip_set_patch_min_rows(int64_t rows) { g_patch_min_rows = rows < 0 ? INT64_MAX : rows; }
 
 void amg_hip_set_default_layout(int32_t layout) {

@@ -162,6 +162,10 @@ void amg_hip_set_dict_rows(int32_t rows_per_lane);
  * solvers keep theirs.  Bit-identical results; tests set 0.                              */
 void amg_hip_set_patch_min_rows(int64_t rows);
 
+/* K-BandChain (coarsest solve kind 3) on / off; process-wide, read when a solver is created.
+ * Same bits either way: an A/B switch for tests and tuning.                             */
+void amg_hip_set_band_chain(int32_t on);
+
 /* Number of usable HIP devices (0 when none; never fails). */
 int amg_hip_device_count(void);
 
@@ -344,7 +348,9 @@ int64_t amg_hip_coarse_halfbw(const amg_hip_solver* s);
 /* Which device form of the coarsest solve (multigrid.hpp:287-288) the solver uses:
  * 0 = one-wave sequential substitution (half-bandwidth <= 63, bit-exact),
  * 1 = partitioned / parallel (fast_coarse_solve or >= 4096 rows),
- * 2 = blocked sequential substitution for any half-bandwidth (bit-exact).          */
+ * 2 = blocked sequential substitution for any half-bandwidth (bit-exact),
+ * 3 = LDS-resident scalar recurrence for half-bandwidth <= 3 and <= 2048 rows (bit-exact;
+ *     the coarsest level of a deep hierarchy).                                        */
 int32_t amg_hip_coarse_solve_kind(const amg_hip_solver* s);
 /* Multicolour smoother: colour of every dof of `level` (n_dofs int32) and the
  * colour count, so a CPU twin can replay the same colouring.                   */

@@ -557,3 +557,47 @@ def test_custom_interpolator_galerkin_on_device_matches_host(amg, oracle):
     assert np.isfinite(dev.rss())
     dev.close()
     host.close()
+
+
+# ---------------------------------------------------------------- K-BandChain (narrow coarsest solve)
+@pytest.mark.parametrize("n,w", [(1, 1), (7, 2), (16, 1), (17, 3), (511, 2), (1000, 3), (2048, 2)])
+def test_band_chain_bit_exact(amg, oracle, n, w):
+    """multigrid.hpp:240-243,287-288 on the narrow coarsest operators of deep hierarchies
+    (half-bandwidth <= 3, <= 2048 rows): the LDS-resident scalar recurrence subtracts the same
+    products in the same order as the one-wave K-Band kernel and the oracle's band solve."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(100 * n + w)
+    w = min(w, max(n - 1, 0))
+    diags = [-(4.0 + rng.random(n))]
+    offs = [0]
+    for d in range(1, w + 1):
+        v = 0.5 + 0.5 * rng.random(n - d)
+        diags += [v, v]
+        offs += [d, -d]
+    M = sp.diags(diags, offs, format="csc") if n > 1 else sp.csc_matrix(np.array([[-4.5]]))
+    M.sort_indices()
+    A = oracle.CSC(n, n, M.indptr, M.indices, M.data)
+    f = rng.standard_normal(n)
+    want, w_ref = oracle.band_solve(A, f)
+    got = {}
+    for on in (True, False):
+        amg.set_band_chain(on)
+        got[on], wg = amg.coarse_solve(*csc(A), f)
+        assert wg == w_ref == w
+    amg.set_band_chain(True)
+    assert np.array_equal(got[True], want) and np.array_equal(got[False], want)
+
+
+def test_headline_hierarchy_uses_band_chain_and_is_unchanged(amg):
+    n, L = 1024, 14                      # coarsest: 127 rows, half-bandwidth 2
+    res = {}
+    for on in (True, False):
+        amg.set_band_chain(on)
+        mg = amg.Multigrid.poisson(n, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
+        assert ("band-chain" in mg.coarse_solve_kind()) == on
+        mg.vcycle(5)
+        res[on] = (mg.get_soln(0), mg.get_soln(L - 1), mg.rss())
+        mg.close()
+    amg.set_band_chain(True)
+    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
+    assert res[True][2] == res[False][2]
