@@ -2656,7 +2656,7 @@ __device__ __forceinline__ void band_chain_fetch(ChainChunk<W>& c, const double*
 template <int W>
 __device__ __forceinline__ void band_chain_steps(const ChainChunk<W>& c, double (&prev)[W], int lane,
                                                  int left, double* out) {
-  double mine = 0.0;
+  double res[CHAIN_CH];
 #pragma unroll
   for (int i = 0; i < CHAIN_CH; ++i) {
     double acc = c.r[i];
@@ -2665,9 +2665,13 @@ __device__ __forceinline__ void band_chain_steps(const ChainChunk<W>& c, double 
 #pragma unroll
     for (int t = 0; t + 1 < W; ++t) prev[t] = prev[t + 1];
     prev[W - 1] = acc;
-    mine = lane == i ? acc : mine;
+    res[i] = acc;
   }
-  if (lane < CHAIN_CH && lane < left) out[lane] = mine;  // one wave: LDS keeps program order
+  if (lane == 0) {  // every lane holds all eight results; one lane stores them (padded array)
+#pragma unroll
+    for (int i = 0; i < CHAIN_CH; ++i) out[i] = res[i];
+  }
+  (void)left;
 }
 template <int W>
 __device__ __forceinline__ void band_chain_pass(int n, const double* ops, double* v) {
@@ -2680,10 +2684,16 @@ __device__ __forceinline__ void band_chain_pass(int n, const double* ops, double
   for (int s0 = 0; s0 < n; s0 += 2 * CHAIN_CH) {
     const double* op = ops + s0 * W;
     double* rv = v + s0;
+    // the next chunk's operands are read BEFORE this chunk's dependent chain starts (and stay
+    // there: sched_barrier), so the LDS latency hides behind it
     band_chain_fetch<W>(B, op + CHAIN_CH * W, rv + CHAIN_CH);
+    __builtin_amdgcn_sched_barrier(0);
     band_chain_steps<W>(A, prev, lane, n - s0, rv);
+    __builtin_amdgcn_sched_barrier(0);
     band_chain_fetch<W>(A, op + 2 * CHAIN_CH * W, rv + 2 * CHAIN_CH);
+    __builtin_amdgcn_sched_barrier(0);
     band_chain_steps<W>(B, prev, lane, n - s0 - CHAIN_CH, rv + CHAIN_CH);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 template <int W>
