@@ -1114,6 +1114,24 @@ __device__ __forceinline__ void patch_stage(const PatchCells& pc, int m, int nty
   }
 }
 
+// The smoothed patch leaves through LDS: 64 consecutive threads write one 512-byte line of the
+// patch, so every store of a wave covers whole, aligned 128-byte lines.  (Stored straight from
+// the stage's registers, a line was split 60 + 4 entries between two waves -- the thread map
+// has 72 columns -- and the PMC write traffic was 1.5 x the vector.)
+template <bool NT>
+__device__ __forceinline__ void patch_copy_out(const double* buf, double* __restrict__ out, int n, int m,
+                                               int j0, int i0) {
+  for (int q = threadIdx.x; q < PATCH_TH * PATCH_TW; q += PATCH_NT) {
+    const int lj = q / PATCH_TW, li = q - lj * PATCH_TW;
+    const int64_t row = (int64_t)(j0 + lj) * m + i0 + li;
+    if (row < (int64_t)n) {
+      const double v = buf[(lj + 4) * PATCH_EC + li + 4];
+      if (NT) __builtin_nontemporal_store(v, out + row);
+      else out[row] = v;
+    }
+  }
+}
+
 // PROLONG: the loaded vector is x + P uH (up-leg); else plain x.
 template <bool PROLONG>
 __device__ __forceinline__ void patch_load(PatchCells& pc, int n, int m, int j0, int i0,
@@ -1225,8 +1243,9 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
     lds_barrier();
   }
   patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
-                                    PATCH_TW + 2, u_out);
+                                    PATCH_TW + 2, nullptr);
   lds_barrier();
+  patch_copy_out<NT>(buf, u_out, n, m, j0, i0);  // the residual stage below only reads until its barrier
   // residual; rows outside the matrix read as 0.0 for the restriction (ZERO)
   patch_stage<UN, true, NT, true>(pc, m, ntypes, buf, U, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW + 1,
                                   r_out);
@@ -1271,7 +1290,9 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_up_kernel(
                                     PATCH_TW + 1, nullptr);
   lds_barrier();
   patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW,
-                                    u_out);
+                                    nullptr);
+  lds_barrier();
+  patch_copy_out<NT>(buf, u_out, n, m, j0, i0);
 }
 
 int patch_un(int un) { return un <= 5 ? 5 : un <= 7 ? 7 : 9; }
