@@ -1132,6 +1132,7 @@ __device__ __forceinline__ void patch_copy_out(const double* buf, double* __rest
   }
 }
 
+struct __attribute__((aligned(8))) PatchPair { double x, y; };  // 16-byte load, 8-byte aligned
 // PROLONG: the loaded vector is x + P uH (up-leg); else plain x.
 template <bool PROLONG>
 __device__ __forceinline__ void patch_load(PatchCells& pc, int n, int m, int j0, int i0,
@@ -1166,7 +1167,12 @@ __device__ __forceinline__ void patch_load(PatchCells& pc, int n, int m, int j0,
       const bool odd = (row & 1) != 0;
       const bool a_ok = pc.live[k] && !odd && j >= 1 && j - 1 < nH;
       const bool b_ok = pc.live[k] && j < nH;
-      const double a = uH[a_ok ? j - 1 : 0], b = uH[b_ok ? j : 0];
+      // uH[j - 1] and uH[j] as ONE 16-byte load of the pair (jc - 1, jc), jc = j clamped to
+      // [1, nH - 1] (nH >= 2 on a patch level): half the load instructions of two gathers
+      const int jc = j < 1 ? 1 : (j > nH - 1 ? nH - 1 : j);
+      const PatchPair pr = *reinterpret_cast<const PatchPair*>(uH + (jc - 1));
+      const double a = (j == jc) ? pr.x : pr.y;   // j - 1 == jc - 1, or j - 1 == jc (j == nH)
+      const double b = (j == jc) ? pr.y : pr.x;   // j == jc, or j == jc - 1 (j == 0)
       double t = 0.0;
       t = a_ok ? t + 0.5 * a : t;
       t = b_ok ? t + (odd ? 1.0 : 0.5) * b : t;
