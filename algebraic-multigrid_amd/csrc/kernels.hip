@@ -1134,8 +1134,10 @@ __device__ __forceinline__ void patch_copy_out(const double* buf, double* __rest
 
 struct __attribute__((aligned(8))) PatchPair { double x, y; };  // 16-byte load, 8-byte aligned
 // PROLONG: the loaded vector is x + P uH (up-leg); else plain x.
-template <bool PROLONG>
-__device__ __forceinline__ void patch_load(PatchCells& pc, int n, int m, int j0, int i0,
+// UNI: every row of the patch and its halo has the row type `tf` (patch_tile_flags_kernel found
+// that out at setup): no row-type loads, no bounds checks, the wave-uniform path for all waves.
+template <bool PROLONG, bool UNI>
+__device__ __forceinline__ void patch_load(PatchCells& pc, uint32_t tf, int n, int m, int j0, int i0,
                                            const double* __restrict__ x,
                                            const double* __restrict__ f,
                                            const uint8_t* __restrict__ rtype, int ntypes,
@@ -1152,11 +1154,11 @@ __device__ __forceinline__ void patch_load(PatchCells& pc, int n, int m, int j0,
 #pragma unroll
   for (int k = 0; k < PATCH_K; ++k) {
     const int64_t r64 = r0 + (int64_t)k * m;
-    pc.live[k] = r64 >= 0 && r64 < (int64_t)n;
+    pc.live[k] = UNI || (r64 >= 0 && r64 < (int64_t)n);
     const int row = pc.live[k] ? (int)r64 : 0;
     xv[k] = x[row];
     pc.f[k] = f[row];
-    pc.ty[k] = rtype[row];
+    pc.ty[k] = UNI ? tf : (uint32_t)rtype[row];
   }
 #pragma unroll
   for (int k = 0; k < PATCH_K; ++k) {
@@ -1183,10 +1185,47 @@ __device__ __forceinline__ void patch_load(PatchCells& pc, int n, int m, int j0,
     pc.ty[k] = (pc.live[k] && pc.ty[k] < nty) ? pc.ty[k] : nty;  // 255 = empty row -> absent row
     pc.f[k] = pc.live[k] ? pc.f[k] : 0.0;
   }
+  if (UNI) {
+    pc.tu = tf;
+    pc.uniform = true;
+    return;
+  }
   pc.tu = (uint32_t)__builtin_amdgcn_readfirstlane((int)pc.ty[0]);
 #pragma unroll
   for (int k = 0; k < PATCH_K; ++k) mism |= pc.ty[k] ^ pc.tu;
   pc.uniform = __builtin_amdgcn_ballot_w64(mism != 0) == 0 && pc.tu < (uint32_t)ntypes;
+}
+
+// flag[tile] = the row type shared by EVERY row a patch kernel loads for the tile (lines
+// -3 .. TH+3, columns -4 .. TW+4 of the flat index, all inside the matrix), else 255.
+__global__ __launch_bounds__(256) void patch_tile_flags_kernel(int n, int m, int px_count,
+                                                               const uint8_t* __restrict__ rtype,
+                                                               int ntypes, uint8_t* __restrict__ flag) {
+  const int tile = blockIdx.x;
+  const int py = tile / px_count, px = tile - py * px_count;
+  const int64_t base = (int64_t)(py * PATCH_TH - 3) * m + px * PATCH_TW - 4;
+  const int64_t first = base < 0 ? 0 : (base < n ? base : n - 1);
+  const uint32_t t0 = rtype[first];
+  int ok = base >= 0 && t0 < (uint32_t)ntypes;
+  for (int q = threadIdx.x; q < PATCH_EH * PATCH_EC; q += 256) {
+    const int le = q / PATCH_EC, c = q - le * PATCH_EC;
+    const int64_t r = base + (int64_t)le * m + c;
+    ok = ok && r >= 0 && r < (int64_t)n && rtype[r < 0 ? 0 : (r < n ? r : n - 1)] == t0;
+  }
+  ok = __syncthreads_and(ok);
+  if (threadIdx.x == 0) flag[tile] = ok ? (uint8_t)t0 : (uint8_t)255;
+}
+hipError_t launch_patch_tile_flags(int64_t n, int64_t m, const uint8_t* rtype, int ntypes, uint8_t* flag,
+                                   int64_t* n_tiles, hipStream_t st) {
+  if (!patch_geometry_ok(n, m)) return hipErrorInvalidValue;
+  const int64_t lines = (n + m - 1) / m;
+  const int pxc = (int)(m / PATCH_TW);
+  const int64_t tiles = (lines + PATCH_TH - 1) / PATCH_TH * pxc;
+  if (n_tiles) *n_tiles = tiles;
+  if (!flag) return hipSuccess;
+  hipLaunchKernelGGL(patch_tile_flags_kernel, dim3((unsigned)tiles), dim3(256), 0, st, (int)n, (int)m, pxc,
+                     rtype, ntypes, flag);
+  return hipGetLastError();
 }
 
 __device__ __forceinline__ void patch_stage_tables(PatchJ* tabJ, PatchR* tabR,
@@ -1231,7 +1270,7 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
     int nent, int ntypes, const double* x, const double* __restrict__ f, double* u_out, double* r_out, int nH,
     double* __restrict__ fH, const double* __restrict__ diagH, double* __restrict__ uH1,
-    double omega, int xcd_map, int py0) {
+    double omega, int xcd_map, int py0, const uint8_t* __restrict__ tflag) {
   __shared__ double buf[PATCH_BUF];
   __shared__ PatchJ tabJ[PATCH_MAXTAB];
   __shared__ PatchR tabR[PATCH_MAXTAB];
@@ -1240,7 +1279,9 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
   const int j0 = (py + py0) * PATCH_TH, i0 = px * PATCH_TW;
   PatchCells pc;
   PatchU U;
-  patch_load<false>(pc, n, m, j0, i0, x, f, rtype, ntypes, nullptr, 0, buf);
+  const uint32_t tf = tflag ? (uint32_t)tflag[(py + py0) * px_count + px] : 255u;
+  if (tf != 255u) patch_load<false, true>(pc, tf, n, m, j0, i0, x, f, rtype, ntypes, nullptr, 0, buf);
+  else patch_load<false, false>(pc, tf, n, m, j0, i0, x, f, rtype, ntypes, nullptr, 0, buf);
   patch_prologue(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U);
   lds_barrier();
   if (FIRST) {
@@ -1280,7 +1321,7 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_up_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
     int nent, int ntypes, const double* x, const double* __restrict__ f, const double* __restrict__ uH, int nH,
-    double* u_out, double omega, int xcd_map, int py0) {
+    double* u_out, double omega, int xcd_map, int py0, const uint8_t* __restrict__ tflag) {
   __shared__ double buf[PATCH_BUF];
   __shared__ PatchJ tabJ[PATCH_MAXTAB];
   __shared__ PatchR tabR[PATCH_MAXTAB];
@@ -1289,7 +1330,9 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_up_kernel(
   const int j0 = (py + py0) * PATCH_TH, i0 = px * PATCH_TW;
   PatchCells pc;
   PatchU U;
-  patch_load<true>(pc, n, m, j0, i0, x, f, rtype, ntypes, uH, nH, buf);
+  const uint32_t tf = tflag ? (uint32_t)tflag[(py + py0) * px_count + px] : 255u;
+  if (tf != 255u) patch_load<true, true>(pc, tf, n, m, j0, i0, x, f, rtype, ntypes, uH, nH, buf);
+  else patch_load<true, false>(pc, tf, n, m, j0, i0, x, f, rtype, ntypes, uH, nH, buf);
   patch_prologue(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U);
   lds_barrier();
   patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
@@ -1345,11 +1388,11 @@ hipError_t launch_patch_down(bool first, int64_t n, int64_t m, const PatchRef& P
     if (first)
       hipLaunchKernelGGL((patch_down_kernel<decltype(U)::value, true, decltype(NTF)::value>), dim3(grid),
                          dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, u_out,
-                         r_out, (int)nH, fH, diagH, uH1, omega, xm, py0);
+                         r_out, (int)nH, fH, diagH, uH1, omega, xm, py0, P.tflag);
     else
       hipLaunchKernelGGL((patch_down_kernel<decltype(U)::value, false, decltype(NTF)::value>), dim3(grid),
                          dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, u_out,
-                         r_out, (int)nH, fH, diagH, uH1, omega, xm, py0);
+                         r_out, (int)nH, fH, diagH, uH1, omega, xm, py0, P.tflag);
   });
 }
 hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double* x, const double* f,
@@ -1365,7 +1408,7 @@ hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double
   return patch_dispatch(P.un, P.nt != 0, [&](auto U, auto NTF) {
     hipLaunchKernelGGL((patch_up_kernel<decltype(U)::value, decltype(NTF)::value>), dim3(grid),
                        dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, uH,
-                       (int)nH, u_out, omega, xm, py0);
+                       (int)nH, u_out, omega, xm, py0, P.tflag);
   });
 }
 int patch_lds_pitch() { return PATCH_EC; }

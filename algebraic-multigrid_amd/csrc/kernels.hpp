@@ -87,8 +87,14 @@ struct PatchRef {
   // slots, mask of slots in use}
   const double* utabd = nullptr;
   const int32_t* utabi = nullptr;
+  // per tile of the level: the row type every row of the tile and its halo has, or 255
+  // (launch_patch_tile_flags); null = always take the general path
+  const uint8_t* tflag = nullptr;
   int nent = 0, ntypes = 0, un = 0, nt = 0;
 };
+// flag == null: only *n_tiles is computed (the size of the array)
+hipError_t launch_patch_tile_flags(int64_t n, int64_t m, const uint8_t* rtype, int ntypes, uint8_t* flag,
+                                   int64_t* n_tiles, hipStream_t st);
 bool patch_geometry_ok(int64_t n, int64_t m);
 int patch_un(int longest_row);
 int patch_lds_pitch();

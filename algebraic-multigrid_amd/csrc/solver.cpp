@@ -235,6 +235,8 @@ hipError_t device_galerkin_generic(const DevCsr& A, const DevCsr& P, const DevCs
   return hipSuccess;
 }
 
+int g_patch_tile_flags = 1;  // amg_hip_set_patch_tile_flags: A/B switch (same bits either way)
+
 // A level matrix on the device in one of the two layouts the kernels take.
 struct DevMat {
   bool sell = false;
@@ -258,10 +260,11 @@ struct DevMat {
   bool patch = false;
   int64_t patch_m = 0;
   int patch_un = 0, patch_ntypes = 0;
-  DevMem patch_tab, patch_utabd, patch_utabi;
+  DevMem patch_tab, patch_utabd, patch_utabi, patch_flags;
   PatchRef patch_ref() const {
     PatchRef P;
     P.rtype = drtype.as<uint8_t>();
+    P.tflag = g_patch_tile_flags ? patch_flags.as<uint8_t>() : nullptr;
     P.ptab = patch_tab.as<double>();
     P.utabd = patch_utabd.as<double>();
     P.utabi = patch_utabi.as<int32_t>();
@@ -442,6 +445,13 @@ hipError_t finish_dict(const DictMat& T, int64_t n, int64_t diag_shift, DevMat* 
       }
       if ((e = upload(D->patch_utabd, ud.data(), ud.size())) != hipSuccess) return e;
       if ((e = upload(D->patch_utabi, ui.data(), ui.size())) != hipSuccess) return e;
+      // which patches consist of one row type only (the interior of the level)
+      int64_t tiles = 0;
+      if ((e = launch_patch_tile_flags(n, D->patch_m, nullptr, nty, nullptr, &tiles, nullptr)) != hipSuccess) return e;
+      if ((e = D->patch_flags.alloc((size_t)tiles)) != hipSuccess) return e;
+      if ((e = launch_patch_tile_flags(n, D->patch_m, D->drtype.as<uint8_t>(), nty,
+                                       D->patch_flags.as<uint8_t>(), nullptr, nullptr)) != hipSuccess) return e;
+      if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
       D->patch = true;
     }
   }
@@ -1866,6 +1876,7 @@ void amg_hip_set_nontemporal(int32_t on) { g_nontemporal = on ? 1 : 0; }
 void amg_hip_set_xcd_mapping(int32_t on) { set_xcd_mapping(on); }
 void amg_hip_set_row_types(int32_t on) { g_row_types = on ? 1 : 0; }
 void amg_hip_set_dict_rows(int32_t rows_per_lane) { set_dict_rows_per_lane(rows_per_lane); }
+void amg_hip_set_patch_tile_flags(int32_t on) { g_patch_tile_flags = on ? 1 : 0; }
 void amg_hip_set_band_chain(int32_t on) { g_no_band_chain = on ? 0 : 1; }
 void amg_hip_set_patch_min_rows(int64_t rows) { g_patch_min_rows = rows < 0 ? INT64_MAX : rows; }
 

@@ -162,6 +162,9 @@ void amg_hip_set_dict_rows(int32_t rows_per_lane);
  * solvers keep theirs.  Bit-identical results; tests set 0.                              */
 void amg_hip_set_patch_min_rows(int64_t rows);
 
+/* K-Patch per-tile row-type flags (patches whose rows all share one type skip the row-type
+ * loads and the bounds checks) on / off; process-wide, read at launch.  Same bits either way. */
+void amg_hip_set_patch_tile_flags(int32_t on);
 /* K-BandChain (coarsest solve kind 3) on / off; process-wide, read when a solver is created.
  * Same bits either way: an A/B switch for tests and tuning.                             */
 void amg_hip_set_band_chain(int32_t on);

@@ -601,3 +601,23 @@ def test_headline_hierarchy_uses_band_chain_and_is_unchanged(amg):
     amg.set_band_chain(True)
     assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
     assert res[True][2] == res[False][2]
+
+
+def test_patch_tile_flags_on_off_identical(amg):
+    """Patches whose rows all share one row type skip the row-type loads and the bounds checks
+    (per-tile flags computed at setup); same bits with the flags ignored."""
+    n, L = 1024, 10
+    out = []
+    amg.set_patch_min_rows(0)
+    for on in (True, False):
+        amg.set_patch_tile_flags(on)
+        mg = amg.Multigrid.poisson(n, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
+        assert mg.profile_fine_sweep(1)[3].startswith("patch_down")
+        mg.vcycle(4)
+        out.append((mg.get_soln(0), mg.get_soln(2), mg.get_rhs(3), mg.rss()))
+        mg.close()
+    amg.set_patch_tile_flags(True)
+    amg.set_patch_min_rows(1 << 20)
+    for a, c in zip(out[0][:3], out[1][:3]):
+        assert np.array_equal(a, c)
+    assert out[0][3] == out[1][3]
