@@ -98,13 +98,20 @@ def test_slab_cycle_equals_single_gpu_cycle(amg, patch_everywhere, world, max_le
     ref.close()
 
 
-def test_slab_full_size_4096_eight_ranks(amg):
-    """BASELINE config 3 cut the way bench.py --gpus 8 cuts it (8 x 512 lines, four slab levels,
-    23 halo lines), all eight ranks' legs run one after the other on this GPU."""
+@pytest.mark.parametrize("pmr,k", [(None, 4), (0, 6)])
+def test_slab_full_size_4096_eight_ranks(amg, pmr, k):
+    """BASELINE config 3 cut into 8 x 512 lines, all eight ranks' legs run one after the other on
+    this GPU: with the single-GPU K-Patch threshold (four slab levels, 23 halo lines) and the way
+    bench.py --gpus 8 cuts it (--slab-patch-min-rows 0: six slab levels, 35 halo lines)."""
     n, L, world = 4096, 16, 8
     ref = amg.Multigrid.poisson(n, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
-    engs, st = _engines(amg, n, L, world, -1)
-    assert int(engs[0].info.levels) == 4 and int(engs[0].info.halo_lines) == 23
+    if pmr is not None:
+        amg.set_patch_min_rows(pmr)
+    try:
+        engs, st = _engines(amg, n, L, world, -1)
+    finally:
+        amg.set_patch_min_rows(1 << 20)
+    assert int(engs[0].info.levels) == k and int(engs[0].info.halo_lines) == 6 * k - 1
     for c in range(3):
         ref.vcycle()
         _cycle(engs, poison=True)
