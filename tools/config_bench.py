@@ -65,6 +65,14 @@ def run_rs(n, sm, cycles=10, theta=0.25, min_coarse=500, dim=2):
     print(f"RS dim={dim} n={n} dofs={n**dim} levels={L} sizes={sizes[:4]}..{sizes[-1]} smoother={sm}: setup {setup:.2f}s, "
           f"{dt*1e3:.3f} ms/V-cycle = {1/dt:.1f} V-cycles/s, coarsest half-bw {mg.coarse_halfbw()}, "
           f"||r|| factor per cycle {fac:.4f}: 1e-8 in {need} cycles = {need*dt*1e3:.1f} ms", flush=True)
+    if sm != "spgs":   # the V-cycle as M^-1 inside CG (reference README.md:127) from a zero guess
+        mg.zero_vec(0, "u")
+        mg.sync()
+        t2 = time.perf_counter()
+        _, it, rel = mg.pcg(1e-8, 200)
+        t3 = time.perf_counter()
+        print(f"   PCG on the same hierarchy: {it} iterations to relative residual {rel:.2e} in {(t3-t2)*1e3:.1f} ms "
+              f"(incl. copying the solution back)", flush=True)
     mg.close()
 
 
