@@ -1008,9 +1008,19 @@ def bench(args):
             else:
                 notes["slab"] = "ran but did not reproduce the p2p result; discarded"
         except amg.AmgHipError as ex:
-            if ex.status != amg.EUNSUPPORTED:
-                raise
-            notes["slab"] = f"unavailable: {ex.message}"   # the same refusal on every rank (host arithmetic)
+            kind = "unavailable" if ex.status == amg.EUNSUPPORTED else "failed"   # EUNSUPPORTED: host arithmetic, every rank alike
+            notes["slab"] = f"{kind}: {ex.message}"
+        except Exception as ex:   # noqa: BLE001 -- a candidate that fails must not cost the line we already have
+            notes["slab"] = f"failed: {type(ex).__name__}: {ex}"
+        try:
+            # every rank must agree that the candidate stands (a rank that failed half way leaves
+            # the others inside a collective: the watchdog, still armed, ends that with status 3)
+            flag = torch.tensor([1 if "slab" in results else 0], dtype=torch.int32,
+                                device="cpu" if rehearsal else be.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and "slab" in results:
+                del results["slab"]
+                notes["slab"] = "discarded: failed or was refused on another rank"
         finally:
             dog.disarm()
 
