@@ -951,46 +951,70 @@ def bench(args):
         # the partition, so two shardings of the same vector may differ in the last digit)
         return a[3] == b[3] and abs(a[2] - b[2]) <= 1e-12 * abs(b[2]) and abs(a[1] - b[1]) <= 1e-12 * abs(b[1])
 
-    # halo exchange through torch.distributed isend/irecv (RCCL): always available
-    dv = DistributedVcycle(hier, b, be, rank, world, omega=args.omega, sweeps=args.sweeps,
-                           dist_min_rows=args.dist_min_rows, host_staged=rehearsal, comm="p2p")
-    results = {"p2p": timed(dv)}
-    # Direct pushes over hipIpc (xGMI), host-driven ("ipc") or inside one hipGraph per
-    # rank ("graph").  A mode is kept only if it sets up on every rank AND reproduces the
-    # p2p result bit for bit (same cycles from the same start => identical rss).  A
-    # watchdog prints the p2p line and leaves if an attempt hangs.
-    notes = {}
+    import json as _json
+    results, notes = {}, {}
     stash = {"json": None}
-
     dog = TransportWatchdog(rank, args.comm_timeout, stash)
-    dvr = None
 
-    # Agglomeration threshold above the fine level: nothing is distributed, every rank runs the
-    # whole (fused, K-Patch) single-GPU cycle redundantly.  With host-driven exchanges
-    # (~80 us each, ~7 per level and cycle) that is the faster configuration whenever a level
-    # takes one GPU less than its exchanges cost -- at 4096^2 always (level 0: 390 us); it is
-    # timed like any other candidate and reported as "replicated" when it wins.
-    if dv.n_dist and args.comm in ("safe", "auto", "p2p"):
-        dvr = DistributedVcycle(hier, b, be, rank, world, omega=args.omega, sweeps=args.sweeps,
-                                dist_min_rows=1 << 62, host_staged=rehearsal, comm="p2p")
-        res = timed(dvr)
-        if same_result(res, results["p2p"]):
-            results["replicated"] = res
-            notes["replicated"] = "ok"
-        else:
-            notes["replicated"] = "did not reproduce the sharded result; discarded"
-        notes["replicated_distributed_levels"] = dvr.n_dist
+    def agree(name):
+        """Every rank must agree that candidate `name` stands (a rank that failed half way leaves
+        the others inside a collective: the watchdog, still armed, ends that with status 3)."""
+        flag = torch.tensor([1 if name in results else 0], dtype=torch.int32,
+                            device="cpu" if rehearsal else be.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and name in results:
+            del results[name]
+            notes[name] = "discarded: failed or was refused on another rank"
+
+    def stash_line(note):
+        best_so_far = min(results, key=lambda k: results[k][0])
+        stash["json"] = _json.dumps(_result_line(args, world, L, dvr, results, best_so_far,
+                                                 dict(notes, note=note), rehearsal, None, None, t0)) if rank == 0 else None
+        stash["dv"], stash["n_dist"] = None, None
+
+    # (1) Replicated: nothing is distributed, every rank runs the whole (fused, K-Patch) single-GPU
+    # cycle.  No data-path exchange at all, so it cannot hang; it is the single-GPU result every
+    # sharded candidate has to reproduce bit for bit, and the line that is printed if one hangs.
+    dvr = DistributedVcycle(hier, b, be, rank, world, omega=args.omega, sweeps=args.sweeps,
+                            dist_min_rows=1 << 62, host_staged=rehearsal, comm="p2p")
+    results["replicated"] = timed(dvr)
+    notes["replicated"] = "ok"
+    notes["replicated_distributed_levels"] = dvr.n_dist
+    ref = results["replicated"]
+
+    # (2) Per-sweep halo exchange through torch.distributed isend/irecv + all_gather (RCCL): one
+    # exchange before every sweep, residual and transfer of the distributed levels.
+    dv = dvr
+    if world > 1:
+        stash_line("p2p exchange hung")
+        dog.arm("p2p")
+        try:
+            if os.environ.get("AMG_DIST_FORCE_HANG") == "p2p":
+                time.sleep(args.comm_timeout + 30)
+            dv = DistributedVcycle(hier, b, be, rank, world, omega=args.omega, sweeps=args.sweeps,
+                                   dist_min_rows=args.dist_min_rows, host_staged=rehearsal, comm="p2p")
+            notes["p2p_distributed_levels"] = dv.n_dist
+            res = timed(dv)
+            if same_result(res, ref):
+                results["p2p"] = res
+                notes["p2p"] = "ok"
+            else:
+                notes["p2p"] = "ran but did not reproduce the single-GPU result; discarded"
+        except Exception as ex:   # noqa: BLE001 -- a candidate that fails must not cost the line we already have
+            notes["p2p"] = f"failed: {type(ex).__name__}: {ex}"
+            dv = dvr
+        try:
+            agree("p2p")
+        finally:
+            dog.disarm()
 
     # Slab sharding (slab_vcycle.py): the K-Patch levels over this rank's grid lines + redundant
     # halo, two exchanges per cycle (grouped send/recv of the level-0 halo lines, one all-gather),
     # the rest replicated.  Same RCCL primitives as "p2p"; kept only if it reproduces its result.
     dvs = None
     if world > 1 and args.comm in ("safe", "auto", "slab") and args.sweeps == 2:
-        import json as _json
         import slab_vcycle
-        stash["json"] = _json.dumps(_result_line(args, world, L, dv, results, min(results, key=lambda k: results[k][0]),
-                                                 dict(notes, note="slab exchange hung"), rehearsal, None, None, t0)) if rank == 0 else None
-        stash["dv"], stash["n_dist"] = None, None
+        stash_line("slab exchange hung")
         dog.arm("slab")
         try:
             if os.environ.get("AMG_DIST_FORCE_HANG") == "slab":
@@ -1002,32 +1026,23 @@ def bench(args):
             notes["slab_distributed_levels"] = dvs.n_dist
             notes["slab_halo_lines"] = int(eng.info.halo_lines)
             res = timed(dvs)
-            if same_result(res, results["p2p"]):
+            if same_result(res, ref):
                 results["slab"] = res
                 notes["slab"] = "ok"
             else:
-                notes["slab"] = "ran but did not reproduce the p2p result; discarded"
+                notes["slab"] = "ran but did not reproduce the single-GPU result; discarded"
         except amg.AmgHipError as ex:
             kind = "unavailable" if ex.status == amg.EUNSUPPORTED else "failed"   # EUNSUPPORTED: host arithmetic, every rank alike
             notes["slab"] = f"{kind}: {ex.message}"
         except Exception as ex:   # noqa: BLE001 -- a candidate that fails must not cost the line we already have
             notes["slab"] = f"failed: {type(ex).__name__}: {ex}"
         try:
-            # every rank must agree that the candidate stands (a rank that failed half way leaves
-            # the others inside a collective: the watchdog, still armed, ends that with status 3)
-            flag = torch.tensor([1 if "slab" in results else 0], dtype=torch.int32,
-                                device="cpu" if rehearsal else be.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0 and "slab" in results:
-                del results["slab"]
-                notes["slab"] = "discarded: failed or was refused on another rank"
+            agree("slab")
         finally:
             dog.disarm()
 
-    if dv.n_dist and args.comm not in ("p2p", "safe", "slab"):
-        import json as _json
-        stash["json"] = _json.dumps(_result_line(args, world, L, dv, results, "p2p", {"note": "alternative exchange hung"},
-                                                 rehearsal, None, None, t0)) if rank == 0 else None
+    if dv.n_dist and "p2p" in results and args.comm not in ("p2p", "safe", "slab"):
+        stash_line("alternative exchange hung")
         # cheaper exchanges pay off on smaller levels (results do not depend on the
         # threshold); the in-graph exchange is timed with two thresholds because the
         # cost of a flag round trip over xGMI cannot be rehearsed on one GPU
@@ -1046,7 +1061,7 @@ def bench(args):
                 notes[mode + "_distributed_levels"] = dvx.n_dist
                 stash["dv"], stash["n_dist"] = dvx, dvx.n_dist
                 res = timed(dvx)
-                same = same_result(res, results["p2p"]) and not dvx.timed_out()
+                same = same_result(res, ref) and not dvx.timed_out()
                 flag = torch.tensor([1 if same else 0], dtype=torch.int32,
                                     device="cpu" if rehearsal else be.device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -1054,7 +1069,7 @@ def bench(args):
                     results[mode] = res
                     notes[mode] = "ok"
                 else:
-                    notes[mode] = "ran but did not reproduce the p2p result; discarded"
+                    notes[mode] = "ran but did not reproduce the single-GPU result; discarded"
                 dvx.close()
             except IpcUnavailable as ex:
                 notes[mode] = f"unavailable: {ex}"
@@ -1064,7 +1079,7 @@ def bench(args):
     best = min(results, key=lambda k: results[k][0])
     dt, rss0, rss = results[best][:3]
     # dominant kernel: this rank's level-0 Jacobi sweep (HIP events on the rank's stream)
-    D = dv.lv[0] if dv.n_dist else None
+    D = dv.lv[0] if (dv.n_dist and best in ("p2p", "ipc", "graph", "graph@8x")) else None
     avg_ms, sweep_bytes = None, None
     if D is not None:
         lo, n = D.A.halo_lo, D.e - D.s
@@ -1080,8 +1095,8 @@ def bench(args):
         sweep_bytes = 12.0 * D.A.nnz + 28.0 * n
     # nothing distributed (replicated, or the threshold left no level to shard): every rank runs
     # the single-GPU solver, and the dominant kernel is that solver's (same object as at N = 1)
-    best_nd = dv.n_dist if best == "p2p" else notes.get(best + "_distributed_levels")
-    whole = (dv if dv.n_dist == 0 else dvr) if best_nd == 0 else None
+    best_nd = notes.get(best + "_distributed_levels")
+    whole = dvr if best_nd == 0 else None
     roof_whole = None
     if best == "slab" or (whole is not None and hasattr(whole.tail, "mg")):
         from bench import fine_sweep_roofline
@@ -1104,8 +1119,9 @@ def bench(args):
                            layout=lay)
         if roof_whole is not None:
             out["roofline"] = roof_whole
-    if dvr is not None:
-        dvr.close()
+    if dv is not dvr:
+        dv.close()
+    dvr.close()
     if dvs is not None:
         dvs.close()
     dist.barrier()

@@ -292,10 +292,11 @@ def main():
     ap.add_argument("--profile-launches", type=int, default=40)
     ap.add_argument("--comm", choices=["safe", "auto", "p2p", "slab", "ipc", "graph"], default="safe",
                     help="multi-GPU halo exchange.  safe (default) = the configurations built on "
-                         "plain RCCL calls only: slab (K-Patch levels over each rank's grid lines + "
-                         "redundant halo: one grouped send/recv and one all-gather per cycle), p2p "
-                         "(a send/recv before every sweep, residual and transfer) and replicated "
-                         "(nothing distributed); the fastest one is reported.  auto = additionally "
+                         "plain RCCL calls only: replicated (nothing distributed: timed first, it is "
+                         "the reference every other one must reproduce), p2p (a send/recv before every "
+                         "sweep, residual and transfer) and slab (K-Patch levels over each rank's grid "
+                         "lines + redundant halo: one grouped send/recv and one all-gather per cycle); "
+                         "the fastest one is reported.  auto = additionally "
                          "ipc (hipIpc pushes + stream memory ops) and graph (pushes + flags as "
                          "kernels, one hipGraph per rank): experimental, never run on real xGMI "
                          "links; bounded by a watchdog that exits with status 3 when one hangs.  "
