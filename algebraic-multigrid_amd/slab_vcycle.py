@@ -62,6 +62,7 @@ class SlabVcycle:
         self.n_dist = int(i.levels) if world > 1 else 0
         self.n0 = int(i.lines) * int(i.pitch0)
         self._cycles_run = 0
+        self._inplace_ok = True
         if world > 1 and (i.line_end - i.line_begin < i.halo_lines):
             raise ValueError("slab sharding: fewer owned lines than the halo depth")
 
@@ -90,8 +91,16 @@ class SlabVcycle:
             vec[:block * self.world].copy_(ho)
         elif vec.device.type == "cpu":   # gloo: no aliasing of input and output
             dist.all_gather_into_tensor(vec[:block * self.world], mine.clone(), group=self.group)
-        else:                            # RCCL in-place all-gather (input = its own block of the output)
-            dist.all_gather_into_tensor(vec[:block * self.world], mine, group=self.group)
+        elif self._inplace_ok:           # RCCL in-place all-gather (input = its own block of the output)
+            try:
+                dist.all_gather_into_tensor(vec[:block * self.world], mine, group=self.group)
+            except (RuntimeError, TypeError, ValueError):
+                # refused at argument checking (before anything is enqueued, hence on every rank
+                # alike): gather from a copy of the block instead
+                self._inplace_ok = False
+                dist.all_gather_into_tensor(vec[:block * self.world], mine.clone(), group=self.group)
+        else:
+            dist.all_gather_into_tensor(vec[:block * self.world], mine.clone(), group=self.group)
 
     def vcycle(self):
         if self.world == 1:
