@@ -1451,6 +1451,73 @@ __global__ __launch_bounds__(256) void dict_gs_color_kernel(
   dict_rows<CSR_GS, WORDS, UN, 1>(s, s.live[0] ? row : 0, tab, u, 1.0, 0, res);
   if (s.live[0]) u[row] = res[0];
 }
+// The whole symmetric pass (colours 0 .. nc-1, then nc-1 .. 0) of a SMALL level in one launch:
+// one workgroup, a barrier between colours (__syncthreads also orders the global accesses of
+// the workgroup).  On the launch-bound levels of a deep hierarchy a pass is 2 nc launches of
+// ~4.6 us each with almost nothing to do; here it is 2 nc barriers.  Same rows, same order of
+// the colours, same row arithmetic: same bits.
+template <int WORDS, int UN>
+__global__ __launch_bounds__(1024) void dict_gs_sweep_kernel(
+    int nc, const int32_t* __restrict__ starts, const uint64_t* __restrict__ codes,
+    const int32_t* __restrict__ rowid, const int32_t* __restrict__ doff,
+    const double* __restrict__ dval, int ntab, const double* __restrict__ f, double* u) {
+  typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+  __shared__ DictEntry tab[256];
+  if (threadIdx.x < 256) dict_stage_table<CSR_GS>(tab, doff, dval, ntab);
+  __syncthreads();
+  for (int phase = 0; phase < 2 * nc; ++phase) {
+    const int c = phase < nc ? phase : 2 * nc - 1 - phase;
+    const int p0 = starts[c], count = starts[c + 1] - p0;
+    for (int k = threadIdx.x; k < count; k += 1024) {
+      const int p = p0 + k;
+      const int row = rowid[p];
+      DictStream<WORDS, 1> s;
+      s.live[0] = row >= 0;
+      s.cw[0][0] = s.cw[0][1] = ~(uint64_t)0;
+      s.ty = 0xFFFFu;
+      s.fi[0] = s.xi[0] = 0.0;
+      if (s.live[0]) {
+        const uint64_t* cp = codes + (int64_t)p * WORDS;
+        if (WORDS == 2) {
+          const u64x2 t = *reinterpret_cast<const u64x2*>(cp);
+          s.cw[0][0] = t.x; s.cw[0][1] = t.y;
+        } else {
+          s.cw[0][0] = cp[0];
+        }
+        s.fi[0] = f[row];
+        s.xi[0] = u[row];
+      }
+      double res[1];
+      dict_rows<CSR_GS, WORDS, UN, 1>(s, s.live[0] ? row : 0, tab, u, 1.0, 0, res);
+      if (s.live[0]) u[row] = res[0];
+    }
+    __syncthreads();  // colour c is complete (and visible) before the next one reads it
+  }
+}
+hipError_t launch_dict_gs_sweep(int nc, const int32_t* starts_dev, int64_t n_storage, int words, int wmax,
+                                const uint64_t* codes, const int32_t* rowid, const int32_t* doff,
+                                const double* dval, int ntab, const double* f, double* u,
+                                hipStream_t st) {
+  if (nc <= 0) return hipSuccess;
+  if (!starts_dev || n_storage >= ((int64_t)1 << 31) - 512 || ntab > 255 || (words != 1 && words != 2) ||
+      wmax > 8 * words)
+    return hipErrorInvalidValue;
+#define AMG_DICT_GSS(W, U)                                                                   \
+  hipLaunchKernelGGL((dict_gs_sweep_kernel<W, U>), dim3(1), dim3(1024), 0, st, nc, starts_dev, \
+                     codes, rowid, doff, dval, ntab, f, u)
+  if (words == 1) {
+    if (wmax <= 3) AMG_DICT_GSS(1, 3);
+    else if (wmax <= 5) AMG_DICT_GSS(1, 5);
+    else if (wmax <= 7) AMG_DICT_GSS(1, 7);
+    else AMG_DICT_GSS(1, 8);
+  } else {
+    if (wmax <= 9) AMG_DICT_GSS(2, 9);
+    else if (wmax <= 12) AMG_DICT_GSS(2, 12);
+    else AMG_DICT_GSS(2, 16);
+  }
+#undef AMG_DICT_GSS
+  return hipGetLastError();
+}
 hipError_t launch_dict_gs_color(int64_t p0, int64_t count, int words, int wmax,
                                 const uint64_t* codes, const int32_t* rowid, const int32_t* doff,
                                 const double* dval, int ntab, const double* f, double* u,

@@ -15,6 +15,12 @@ enum CsrMode {
   CSR_JACOBI_P = 5 // Jacobi sweep whose input is x + P*uH (linear P), K-SELL only
 };
 
+// one workgroup runs the whole symmetric pass over all colours (small levels); starts_dev:
+// nc + 1 storage-row offsets on the device
+hipError_t launch_dict_gs_sweep(int nc, const int32_t* starts_dev, int64_t n_storage, int words, int wmax,
+                                const uint64_t* codes, const int32_t* rowid, const int32_t* doff,
+                                const double* dval, int ntab, const double* f, double* u,
+                                hipStream_t st);
 // max_block_nnz: max entries in any 256-row block; max_row_nnz: longest row.
 hipError_t launch_csr(int mode, int64_t n, int64_t nnz, int max_block_nnz,
                       int max_row_nnz, const int32_t* rowptr, const int32_t* col,

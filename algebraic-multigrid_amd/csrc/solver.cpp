@@ -602,6 +602,9 @@ constexpr int64_t GS_SCAN_MIN_GAP = 4;
 // serial substitution costs ~44 ns per row and pass; from this size on the partitioned
 // solve is the default (opt.exact_coarse_solve keeps the bit-exact one)
 constexpr int64_t COARSE_SPIKE_MIN_ROWS = 4096;
+// multicolour GS: levels of at most this many rows run a whole symmetric pass as ONE launch
+// (one workgroup, barriers between the colours) instead of one launch per colour and direction
+constexpr int64_t MC_ONE_LAUNCH_MAX_ROWS = 8192;
 // want_fast: 1 = partitioned whenever it applies, 0 = by size, -1 = never
 amg_hip_status upload_coarse(const Sparse& A, int want_fast, CoarseOnDev* C) {
   BandFactor F;
@@ -751,6 +754,7 @@ struct Level {
   DevMat mc_mat;
   DevMem mc_rowid;
   std::vector<int64_t> mc_start;
+  DevMem mc_start_dev;  // the same offsets as int32 on the device (small levels: one-launch pass)
   bool mc_dict = false;    // ... dictionary-coded instead (K-Dict colour kernel)
   int mc_words = 0, mc_wmax = 0, mc_ntab = 0;
   DevMem mc_codes, mc_doff, mc_dval;
@@ -963,8 +967,15 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
 }
 
 // one symmetric pass: colours 0..nc-1 then nc-1..0
-amg_hip_status enqueue_multicolor(amg_hip_solver*, Level& L, hipStream_t st) {
+amg_hip_status enqueue_multicolor(amg_hip_solver* s, Level& L, hipStream_t st) {
   const DevMat& A = L.mc_mat;
+  if (L.mc_dict && L.mc_start_dev.p && !s->opt.no_fusion) {  // small level: the whole pass in one launch
+    HIP_TRY(launch_dict_gs_sweep(L.n_colors, L.mc_start_dev.as<int32_t>(), L.mc_start.back(), L.mc_words,
+                                 L.mc_wmax, L.mc_codes.as<uint64_t>(), L.mc_rowid.as<int32_t>(),
+                                 L.mc_doff.as<int32_t>(), L.mc_dval.as<double>(), L.mc_ntab,
+                                 L.f.as<double>(), L.u.as<double>(), st));
+    return AMG_HIP_OK;
+  }
   auto one = [&](int c) -> hipError_t {
     if (L.mc_dict)
       return launch_dict_gs_color(L.mc_start[c], L.mc_start[c + 1] - L.mc_start[c], L.mc_words,
@@ -1372,6 +1383,10 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
       }
       HIP_TRY(upload(L.mc_rowid, CP.rowid.data(), CP.rowid.size()));
       L.mc_start = CP.start;
+      if (L.mc_dict && L.n <= MC_ONE_LAUNCH_MAX_ROWS) {
+        std::vector<int32_t> st32(CP.start.begin(), CP.start.end());
+        HIP_TRY(upload(L.mc_start_dev, st32.data(), st32.size()));
+      }
     }
     }  // dev
     if (!dev && s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS)
