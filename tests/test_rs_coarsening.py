@@ -105,3 +105,28 @@ def test_argument_checks_and_stopping_rules(oracle):
                                     host_only=True)
     assert mg.n_levels == 1
     mg.close()
+
+
+def test_c_abi_argument_validation_without_device():
+    import ctypes as C
+    import amg_ctypes as amg
+    lib = amg.lib()
+    info = amg.SlabInfo()
+    # slab plan: pure host arithmetic, every refusal is a status, never a crash
+    assert lib.amg_hip_slab_plan(4096, 0, 0, 4, C.byref(info)) == amg.EINVAL        # world < 1
+    assert lib.amg_hip_slab_plan(4096, 3, 2, 4, C.byref(info)) == amg.EINVAL        # rank >= world
+    assert lib.amg_hip_slab_plan(4096, 0, 2, 0, C.byref(info)) == amg.EINVAL        # no slab level
+    assert lib.amg_hip_slab_plan(4096, 0, 2, 9, C.byref(info)) == amg.EINVAL        # > AMG_HIP_SLAB_MAX_LEVELS
+    assert lib.amg_hip_slab_plan(4096, 0, 2, 4, None) == amg.EINVAL
+    assert lib.amg_hip_slab_plan(40, 0, 2, 4, C.byref(info)) == amg.EUNSUPPORTED     # 20 lines per rank < 23
+    assert b"halo depth" in lib.amg_hip_last_error()
+    assert lib.amg_hip_slab_plan(4096, 1, 2, 1, C.byref(info)) == amg.OK and info.halo_lines == 5
+    assert lib.amg_hip_slab_run(None, 1) == amg.EINVAL
+    assert lib.amg_hip_slab_setup(None, 0, 1, -1, C.byref(info)) == amg.EINVAL
+    # create_rs: null arrays / null out handle
+    h = C.c_void_p()
+    o = amg.Options()
+    lib.amg_hip_default_options(C.byref(o))
+    o.host_only = 1
+    assert lib.amg_hip_create_rs(4, None, None, None, None, 3, 0.25, 10, C.byref(o), C.byref(h)) == amg.EINVAL
+    assert lib.amg_hip_create_rs(4, None, None, None, None, 3, 0.25, 10, C.byref(o), None) == amg.EINVAL
