@@ -535,6 +535,14 @@ class Multigrid:
         _chk(lib().amg_hip_fine_sweep_info(self._h, name, 256, C.byref(k), C.byref(nb)))
         return a.value, b.value, k.value, name.value.decode(), nb.value
 
+    def fine_sweep_info(self):
+        """(kernel name, sweeps per launch, bytes one launch has to move) of the level-0 smoother
+        launch (amg_hip_fine_sweep_info); no launch is made."""
+        name = C.create_string_buffer(256)
+        k, nb = C.c_int32(0), C.c_double(0)
+        _chk(lib().amg_hip_fine_sweep_info(self._h, name, 256, C.byref(k), C.byref(nb)))
+        return name.value.decode(), k.value, nb.value
+
     def coarse_solve_kind(self):
         return {0: "band (one wave, sequential, bit-exact)", 1: "spike (partitioned, parallel)",
                 2: "band-wide (blocked sequential, any half-bandwidth, bit-exact)",

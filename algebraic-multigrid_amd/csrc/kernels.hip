@@ -968,7 +968,7 @@ __device__ __forceinline__ void patch_load_u(PatchU& U, uint32_t tu, const doubl
 // have weight +0.0: adding (+0.0) x leaves a Jacobi accumulator's bits alone for finite x (see
 // dict_rows); the residual selects them away.  CORNERS = false: the four corner slots are
 // not even read (5-point level).
-template <bool RESID, bool CORNERS>
+template <bool RESID, bool CORNERS, bool GS = false>
 __device__ __forceinline__ void patch_eval_u(const double* buf, int cell0, const PatchU& U,
                                              const double (&f)[PATCH_K], double omega,
                                              double (&res)[PATCH_K]) {
@@ -1011,7 +1011,7 @@ __device__ __forceinline__ void patch_eval_u(const double* buf, int cell0, const
         res[k] = xi;
       } else {
         const double q = (f[k] - acc) / U.diag;  // smoother.hpp:136
-        res[k] = xi + omega * (q - xi);
+        res[k] = GS ? q : xi + omega * (q - xi);      // GS: the Gauss-Seidel update itself (K-SELL CSR_GS)
       }
     }
 #pragma unroll
@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void patch_eval_u(const double* buf, int cell0, const
 
 // Row arithmetic of dict_rows, per-lane table entries from the LDS copy (mixed row types:
 // level boundaries).
-template <int UN, bool RESID>
+template <int UN, bool RESID, bool GS = false>
 __device__ __forceinline__ double patch_eval(const double* buf, int cell, uint32_t type,
                                              const PatchJ* tabJ, const PatchR* tabR, double fi,
                                              double omega) {
@@ -1065,7 +1065,7 @@ __device__ __forceinline__ double patch_eval(const double* buf, int cell, uint32
   }
   const bool nod = diag == 0.0;
   const double q = (fi - acc) / (nod ? 1.0 : diag);  // smoother.hpp:136
-  return nod ? xi : xi + omega * (q - xi);
+  return nod ? xi : (GS ? q : xi + omega * (q - xi));
 }
 
 // one stage over the region lines [l0, l1) x columns [c0, c1), IN PLACE in the workgroup's one
@@ -1344,6 +1344,100 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_up_kernel(
   patch_copy_out<NT>(buf, u_out, n, m, j0, i0);
 }
 
+// ---- red-black Gauss-Seidel on a patch (multicolour smoother, 2-colour levels) ------------
+// One colour of a Gauss-Seidel half-sweep as a patch stage: cells of colour `cpar` inside the
+// region take (f - sum of off-diagonal terms) / diagonal from the CURRENT neighbours (which all
+// have the other colour), every other cell keeps its value.  parbits: bit k = colour of cell k.
+template <int UN>
+__device__ __forceinline__ void patch_stage_color(const PatchCells& pc, int ntypes, double* buf,
+                                                  const PatchU& U, const PatchJ* tabJ, const PatchR* tabR,
+                                                  int l0, int l1, int c0, int c1, uint32_t parbits,
+                                                  uint32_t cpar) {
+  const bool inc = pc.li >= c0 && pc.li < c1;
+  double res[PATCH_K];
+  bool did[PATCH_K];
+#pragma unroll
+  for (int k = 0; k < PATCH_K; ++k) {
+    const int lj = pc.lj0 + k;
+    did[k] = inc && lj >= l0 && lj < l1 && pc.live[k] && ((parbits >> k) & 1u) == cpar;
+  }
+  if (pc.uniform) {
+    if (U.corners) patch_eval_u<false, true, true>(buf, pc.cell0, U, pc.f, 1.0, res);
+    else patch_eval_u<false, false, true>(buf, pc.cell0, U, pc.f, 1.0, res);
+  } else {
+#pragma unroll
+    for (int k = 0; k < PATCH_K; ++k)
+      res[k] = patch_eval<UN, false, true>(buf, pc.cell0 + k * PATCH_EC,
+                                           did[k] ? pc.ty[k] : (uint32_t)ntypes, tabJ, tabR, pc.f[k], 1.0);
+  }
+  // cells of one colour do not read each other: no barrier between the reads and the writes
+#pragma unroll
+  for (int k = 0; k < PATCH_K; ++k)
+    if (did[k]) buf[pc.cell0 + k * PATCH_EC] = res[k];
+}
+
+// Two colour stages (first colour c_first, then the other) on the loaded patch -- half of the
+// symmetric pass 0,1,1,0 -- in the frame of the Jacobi kernels above:
+//   !TAIL: like the up-leg: [u + P u_H while loading when PROLONG], stage, stage, store;
+//    TAIL: like the level-0 down-leg: stage, stage, store, residual, restriction (f_H; the
+//          coarse u is zeroed, multigrid.hpp:278).
+// colour(row) = ((row / m + row % m) & 1) ^ cb (the checkerboard the greedy colouring yields on
+// the 5-point level; verified on the host).  Same row arithmetic as the colour kernels
+// (dict_rows<CSR_GS>): ascending-column sum of the off-diagonal terms, IEEE divide.
+template <int UN, bool NT, bool PROLONG, bool TAIL>
+__global__ __launch_bounds__(PATCH_NT, 7) void patch_rb_kernel(
+    int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
+    const double* __restrict__ utabd, const int32_t* __restrict__ utabi, int nent, int ntypes,
+    const double* x, const double* __restrict__ f, const double* __restrict__ uH, int nH, double* u_out,
+    double* r_out, double* __restrict__ fH, double* __restrict__ uH_zero, uint32_t c_first, uint32_t cb,
+    int xcd_map, int py0, const uint8_t* __restrict__ tflag) {
+  __shared__ double buf[PATCH_BUF];
+  __shared__ PatchJ tabJ[PATCH_MAXTAB];
+  __shared__ PatchR tabR[PATCH_MAXTAB];
+  const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
+  const int py = tile / px_count, px = tile - py * px_count;
+  const int j0 = (py + py0) * PATCH_TH, i0 = px * PATCH_TW;
+  PatchCells pc;
+  PatchU U;
+  const uint32_t tf = tflag ? (uint32_t)tflag[(py + py0) * px_count + px] : 255u;
+  if (tf != 255u) patch_load<PROLONG, true>(pc, tf, n, m, j0, i0, x, f, rtype, ntypes, uH, nH, buf);
+  else patch_load<PROLONG, false>(pc, tf, n, m, j0, i0, x, f, rtype, ntypes, uH, nH, buf);
+  patch_prologue(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U);
+  uint32_t parbits = 0;
+  {
+    const int col = i0 + pc.li;
+    const uint32_t base = (uint32_t)(j0 + pc.lj0 + col + ((col < 0 || col >= m) ? 1 : 0) + 64) ^ cb;
+#pragma unroll
+    for (int k = 0; k < PATCH_K; ++k) parbits |= ((base + (uint32_t)k) & 1u) << k;
+  }
+  lds_barrier();
+  constexpr int E = TAIL ? 1 : 0;  // the residual stage needs one more ring
+  patch_stage_color<UN>(pc, ntypes, buf, U, tabJ, tabR, -1 - E, PATCH_TH + 1 + E, -1 - E,
+                        PATCH_TW + 1 + 2 * E, parbits, c_first & 1u);
+  lds_barrier();
+  patch_stage_color<UN>(pc, ntypes, buf, U, tabJ, tabR, -E, PATCH_TH + E, -E, PATCH_TW + 2 * E, parbits,
+                        (c_first & 1u) ^ 1u);
+  lds_barrier();
+  patch_copy_out<NT>(buf, u_out, n, m, j0, i0);
+  if (TAIL) {
+    patch_stage<UN, true, NT, true>(pc, m, ntypes, buf, U, tabJ, tabR, 1.0, 0, PATCH_TH, 0, PATCH_TW + 1,
+                                    r_out);
+    lds_barrier();
+    for (int q = threadIdx.x; q < PATCH_TH * (PATCH_TW / 2); q += PATCH_NT) {
+      const int lj = q / (PATCH_TW / 2), cx = q - lj * (PATCH_TW / 2);
+      const int64_t i = (int64_t)(j0 + lj) * m + i0 + 2 * cx;   // fine row 2c
+      const int64_t c = i >> 1;
+      if (i >= (int64_t)n || c >= nH) continue;
+      const double* rs = buf + (lj + 4) * PATCH_EC + 2 * cx + 4;
+      double sum = 0.0;  // dict_restrict_tail / linear_restrict_kernel, same guards and order
+      if (i < n) sum += 0.5 * rs[0];
+      if (i + 1 < n) sum += 1.0 * rs[1];
+      if (i + 2 < n) sum += 0.5 * rs[2];
+      fH[c] = sum;
+      if (uH_zero) uH_zero[c] = 0.0;  // multigrid.hpp:278
+    }
+  }
+}
 int patch_un(int un) { return un <= 5 ? 5 : un <= 7 ? 7 : 9; }
 bool patch_geometry_ok(int64_t n, int64_t m) {
   return m >= 2 * PATCH_TW && (m % PATCH_TW) == 0 && n >= m && n < ((int64_t)1 << 31) - 4 * m - 64;
@@ -1409,6 +1503,29 @@ hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double
     hipLaunchKernelGGL((patch_up_kernel<decltype(U)::value, decltype(NTF)::value>), dim3(grid),
                        dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, uH,
                        (int)nH, u_out, omega, xm, py0, P.tflag);
+  });
+}
+hipError_t launch_patch_rb(bool prolong, bool tail, int64_t n, int64_t m, const PatchRef& P, const double* x,
+                           const double* f, const double* uH, int64_t nH, double* u_out, double* r_out,
+                           double* fH, double* uH_zero, int c_first, int cb, hipStream_t st,
+                           int64_t line_lo, int64_t line_hi) {
+  if (!patch_geometry_ok(n, m) || !P.rtype || !P.ptab || !P.utabd || !P.utabi || (P.ntypes + 1) * patch_un(P.un) > PATCH_MAXTAB ||
+      P.nent != P.ntypes * patch_un(P.un) || !u_out || u_out == x || (prolong && (!uH || tail)) || (tail && !fH) || nH < 2)
+    return hipErrorInvalidValue;
+  int pxc = 0, py0 = 0;
+  const unsigned grid = patch_grid(n, m, line_lo, line_hi, &pxc, &py0);
+  if (grid == 0) return hipSuccess;
+  const int xm = g_xcd_map ? 1 : 0;
+  return patch_dispatch(P.un, P.nt != 0, [&](auto U, auto NTF) {
+#define AMG_RB(PRO, TL)                                                                              \
+  hipLaunchKernelGGL((patch_rb_kernel<decltype(U)::value, decltype(NTF)::value, PRO, TL>), dim3(grid), \
+                     dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi,    \
+                     P.nent, P.ntypes, x, f, uH, (int)nH, u_out, r_out, fH, uH_zero, (uint32_t)c_first,  \
+                     (uint32_t)cb, xm, py0, P.tflag)
+    if (tail) AMG_RB(false, true);
+    else if (prolong) AMG_RB(true, false);
+    else AMG_RB(false, false);
+#undef AMG_RB
   });
 }
 int patch_lds_pitch() { return PATCH_EC; }

@@ -118,6 +118,14 @@ int patch_tile_lines();
 hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double* x, const double* f,
                            const double* uH, int64_t nH, double* u_out, double omega,
                            hipStream_t st, int64_t line_lo = 0, int64_t line_hi = -1);
+// Red-black Gauss-Seidel on patches (2-colour levels of the multicolour smoother): two colour
+// stages, first colour c_first then the other, u_out != x.  prolong: the input is x + P uH;
+// tail: followed by the residual (r_out optional), the restriction into fH and the zeroing of
+// uH_zero (optional).  colour(row) = ((row / m + row % m) & 1) ^ cb.
+hipError_t launch_patch_rb(bool prolong, bool tail, int64_t n, int64_t m, const PatchRef& P, const double* x,
+                           const double* f, const double* uH, int64_t nH, double* u_out, double* r_out,
+                           double* fH, double* uH_zero, int c_first, int cb, hipStream_t st,
+                           int64_t line_lo = 0, int64_t line_hi = -1);
 // uh_out = uh_in + P uH for the linear interpolation pair (16-byte aligned vectors)
 hipError_t launch_linear_prolong_to(int64_t n_h, int64_t n_H, const double* uH,
                                     const double* uh_in, double* uh_out, hipStream_t st);

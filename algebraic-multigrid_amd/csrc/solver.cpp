@@ -750,6 +750,7 @@ struct Level {
   int scan_C = 0, scan_ring = 0;  // > 0: the lexicographic sweeps run as K-GS-scan
   // multicolour: colour-permuted SELL-64 copy + dof of every storage row
   std::vector<int32_t> color;
+  int mc_checker = -1;  // 2 colours laid out as the checkerboard of the level's 2-D band: colour of row 0, else -1
   int32_t n_colors = 0;
   DevMat mc_mat;
   DevMem mc_rowid;
@@ -856,6 +857,17 @@ bool patch_level_ok(const amg_hip_solver* s, int l) {
         L.n >= s->patch_min_rows && s->lv[l + 1].diag.p != nullptr))
     return false;
   return l == 0 || patch_level_ok(s, l - 1);
+}
+
+// Multicolour smoother on a 2-colour (checkerboard) level: the symmetric pass as patch stages,
+// the residual + restriction and the prolongation fused into them (kernels.hip: patch_rb_kernel)
+bool mc_patch_ok(const amg_hip_solver* s, int l) {
+  if (l < 0 || l + 1 >= (int)s->lv.size()) return false;
+  const Level& L = s->lv[l];
+  const DevMat& A = L.A_rows;
+  return s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS && s->opt.smoother_iters == 1 && !s->opt.no_fusion &&
+         L.symmetric && A.dict && A.dict_shift == 0 && A.patch && L.linear && s->opt.stencil_transfers &&
+         L.n >= s->patch_min_rows && L.mc_checker >= 0 && s->lv[l + 1].n >= 2;
 }
 
 // up: last post-smoothing sweep of level l+1 + prolongation into level l
@@ -1025,6 +1037,18 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
     // u with the direct solve of the level's rhs (multigrid.hpp:268-274, :287-288): unless
     // the residual is to be kept, neither has an observable effect.
     if (l == nl - 1 && nl > 1 && !s->opt.keep_residual) break;
+    if (mc_patch_ok(s, l)) {  // :268 (colours 0,1 then 1,0) + :272-282, two launches
+      Level& L = s->lv[l];
+      Level& C = s->lv[l + 1];
+      const DevMat& A = L.A_rows;
+      HIP_TRY(launch_patch_rb(false, false, L.n, A.patch_m, A.patch_ref(), L.u.as<double>(), L.f.as<double>(),
+                              nullptr, C.n, L.tmp.as<double>(), nullptr, nullptr, nullptr, 0, L.mc_checker, st));
+      HIP_TRY(launch_patch_rb(false, true, L.n, A.patch_m, A.patch_ref(), L.tmp.as<double>(), L.f.as<double>(),
+                              nullptr, C.n, L.u.as<double>(), s->opt.keep_residual ? L.r.as<double>() : nullptr,
+                              C.f.as<double>(), C.u.as<double>(), 1, L.mc_checker, st));
+      first_sweep_done = false;
+      continue;
+    }
     if (patch_level_ok(s, l)) {  // :268 (both sweeps) + :272-282 + :268 of l+1, one launch
       Level& L = s->lv[l];
       Level& C = s->lv[l + 1];
@@ -1102,6 +1126,15 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
   for (int l = up_from; l >= up_to; --l) {                         // :291
     Level& L = s->lv[l];
     Level& C = s->lv[l + 1];
+    if (mc_patch_ok(s, l)) {  // :294-296 + :300 (colours 0,1 then 1,0), two launches
+      const DevMat& A = L.A_rows;
+      HIP_TRY(launch_patch_rb(true, false, L.n, A.patch_m, A.patch_ref(), L.u.as<double>(), L.f.as<double>(),
+                              C.u.as<double>(), C.n, L.tmp.as<double>(), nullptr, nullptr, nullptr, 0,
+                              L.mc_checker, st));
+      HIP_TRY(launch_patch_rb(false, false, L.n, A.patch_m, A.patch_ref(), L.tmp.as<double>(), L.f.as<double>(),
+                              nullptr, C.n, L.u.as<double>(), nullptr, nullptr, nullptr, 1, L.mc_checker, st));
+      continue;
+    }
     if (patch_level_ok(s, l)) {  // :294-296 + :300 (both sweeps), one launch
       // level 0 rests in u (its down-leg wrote tmp); coarser patch levels end in tmp
       const DevMat& A = L.A_rows;
@@ -1364,6 +1397,16 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
       HIP_TRY(upload_lex(F, L.lex_fwd.get()));
     } else if (s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS) {
       greedy_coloring(L.A_csc, &L.color, &L.n_colors);
+      // K-Patch form of the pass (patch_rb_kernel) needs colour(row) = parity of (line + column)
+      L.mc_checker = -1;
+      if (L.n_colors == 2 && L.A_rows.patch && L.symmetric) {
+        const int64_t m = L.A_rows.patch_m;
+        const int32_t c0 = L.color[0];
+        bool ok = true;
+        for (int64_t i = 0; i < L.n && ok; ++i)
+          ok = L.color[i] == (int32_t)((((i / m) + (i % m)) & 1) ^ c0);
+        if (ok) L.mc_checker = c0;
+      }
       ColorPerm CP;
       build_color_perm(L.A_csc, L.color, L.n_colors, &CP);  // column-as-row walk, like SpGS
       if (CP.rows.n_outer >= ((int64_t)1 << 31) - 512)
@@ -2520,7 +2563,18 @@ amg_hip_status amg_hip_fine_sweep_info(const amg_hip_solver* s, char* name, int3
   int sweeps = 1;
   // bytes one launch has to move: what it reads and writes once, not a layout it does not stream
   double bytes = 12.0 * (double)L.nnz_struct + 28.0 * (double)L.n;  // SELL / CSR: SURVEY 8(d)
-  if (A.dict && patch_level_ok(s, 0)) {
+  if (s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS) {
+    // one launch of the symmetric pass: two colour stages over the level (patch form), or one
+    // colour of one direction (colour kernels: half the rows)
+    if (mc_patch_ok(s, 0)) {
+      std::snprintf(name, (size_t)name_cap, "patch_rb_kernel<%d, %s, false, false>", patch_un(A.patch_un),
+                    A.dict_nt ? "true" : "false");
+      bytes = 25.0 * (double)L.n;
+    } else {
+      std::snprintf(name, (size_t)name_cap, "%s", L.mc_dict ? "dict_gs_color_kernel" : "sell_kernel<5>");
+      bytes = 0.5 * (12.0 * (double)L.nnz_struct + 28.0 * (double)L.n);
+    }
+  } else if (A.dict && patch_level_ok(s, 0)) {
     // row types + x + f + smoothed u per fine row; f_H, first coarse sweep, coarse diagonal
     std::snprintf(name, (size_t)name_cap, "patch_down_kernel<%d, true, %s>", patch_un(A.patch_un),
                   A.dict_nt ? "true" : "false");

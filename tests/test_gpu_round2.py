@@ -621,3 +621,54 @@ def test_patch_tile_flags_on_off_identical(amg):
     for a, c in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(a, c)
     assert out[0][3] == out[1][3]
+
+
+# ---------------------------------------------------------------- red-black GS as patch stages
+def test_multicolor_patch_form_bit_exact(amg, oracle):
+    """Multicolour smoother on the 2-colour (checkerboard) fine level: the symmetric pass 0,1,1,0
+    runs as two launches of two colour stages each on 2-D patches, with the residual +
+    restriction and the prolongation fused in (patch_rb_kernel).  Same row arithmetic as the
+    colour kernels: every level vector equals the oracle twin's, bit for bit."""
+    n, L = 256, 5
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    amg.set_patch_min_rows(0)
+    try:
+        mg = amg.Multigrid(A.colptr, A.rowind, A.val, b, L, smoother=amg.SM_MULTICOLOR_GS, smoother_iters=1,
+                           exact_coarse_solve=True, keep_residual=True)
+    finally:
+        amg.set_patch_min_rows(1 << 20)
+    assert mg.fine_sweep_info()[0].startswith("patch_rb_kernel")
+    ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_MULTICOLOR, smoother_iters=1)
+    for l in range(L):
+        col, nc = mg.get_colors(l)
+        ref.set_colors(l, col, nc)
+        assert l > 0 or nc == 2
+    for c in range(3):
+        ref.vcycle()
+        mg.vcycle()
+        for l in range(L):
+            if l < L - 1:
+                assert np.array_equal(mg.get_soln(l), ref.get_vec(l, "u")), (c, l)
+            assert np.array_equal(mg.get_rhs(l), ref.get_vec(l, "f")), (c, l)
+            assert np.array_equal(mg.get_residual(l), ref.get_vec(l, "r")), (c, l)
+    mg.close()
+
+
+def test_multicolor_patch_form_equals_colour_kernels_2048(amg):
+    """A/B at 2048^2 / 8 levels, non-zero start: the patch form against one launch per colour
+    (no_fusion), bitwise."""
+    n, L = 2048, 8
+    cp, ri, v = amg.laplacian(n)
+    b = amg.rhs(n)
+    u0 = np.random.default_rng(9).standard_normal(n * n)
+    out = []
+    for nf in (False, True):
+        mg = amg.Multigrid(cp, ri, v, b, L, smoother=amg.SM_MULTICOLOR_GS, smoother_iters=1, no_fusion=nf)
+        assert mg.fine_sweep_info()[0].startswith("patch_rb_kernel") != nf
+        mg.set_vec(0, "u", u0)
+        mg.vcycle(3)
+        out.append((mg.get_soln(0), mg.get_soln(1), mg.get_rhs(1), mg.rss()))
+        mg.close()
+    for a, c in zip(out[0][:3], out[1][:3]):
+        assert np.array_equal(a, c)
+    assert out[0][3] == out[1][3]
