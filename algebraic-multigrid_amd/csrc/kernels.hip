@@ -63,8 +63,8 @@ template <int MODE, int K, int U>
 __global__ __launch_bounds__(CSR_BLOCK) void csr_stage_kernel(
     int64_t n, int64_t nnz, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const double* __restrict__ val,
-    const double* __restrict__ x, const double* __restrict__ f,
-    double* __restrict__ out, double omega, int64_t diag_shift) {
+    const double* __restrict__ x, const double* f,  // f may be out (CSR_SPMV_ADD in place)
+    double* out, double omega, int64_t diag_shift) {
   constexpr int CAP = CSR_BLOCK * K;  // entries staged per chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds_val = reinterpret_cast<double*>(smem);                    // CAP + 4
@@ -153,6 +153,8 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_stage_kernel(
   if (live) {
     if (MODE == CSR_RESID || MODE == CSR_SPMV) {
       out[row] = acc;
+    } else if (MODE == CSR_SPMV_ADD) {
+      out[row] = fi + acc;  // t = P u_H summed from 0, then u_h + t: the reference's two statements
     } else if (MODE == CSR_JACOBI) {
       out[row] = (diag == 0.0) ? xi : xi + omega * ((fi - acc) / diag - xi);
     } else {  // CSR_RSSQ: (b - bhat)^2, common.hpp:24
@@ -214,6 +216,9 @@ hipError_t launch_csr(int mode, int64_t n, int64_t nnz, int max_block_nnz,
     case CSR_RSSQ:
       return launch_csr_mode<CSR_RSSQ>(n, nnz, max_block_nnz, max_row_nnz, rowptr, col,
                                        val, x, f, out, omega, diag_shift, st);
+    case CSR_SPMV_ADD:
+      return launch_csr_mode<CSR_SPMV_ADD>(n, nnz, max_block_nnz, max_row_nnz, rowptr, col,
+                                           val, x, f, out, omega, diag_shift, st);
   }
   return hipErrorInvalidValue;
 }

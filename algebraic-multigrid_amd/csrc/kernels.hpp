@@ -12,7 +12,9 @@ enum CsrMode {
   CSR_SPMV = 2,    // out = A x
   CSR_RSSQ = 3,    // out_i = (f_i - (A x)_i)^2
   CSR_GS = 4,      // in-place Gauss-Seidel update of one colour
-  CSR_JACOBI_P = 5 // Jacobi sweep whose input is x + P*uH (linear P), K-SELL only
+  CSR_JACOBI_P = 5,// Jacobi sweep whose input is x + P*uH (linear P), K-SELL only
+  CSR_SPMV_ADD = 6 // out = f + A x (f may be out: the prolongation-and-add u_h = u_h + P u_H of a
+                   // custom interpolator, multigrid.hpp:294-296, in one launch), K-CSR only
 };
 
 // one workgroup runs the whole symmetric pass over all colours (small levels); starts_dev:

@@ -1161,11 +1161,10 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
       else
         HIP_TRY(launch_linear_prolong_add(L.n, C.n, C.u.as<double>(), L.u.as<double>(), st));
     } else {
-      const DevCsr& P = L.P_rows;
-      HIP_TRY(launch_csr(CSR_SPMV, P.n_rows, P.nnz, P.max_block_nnz, P.max_row_nnz,
-                         P.rowptr(), P.col(), P.v(), C.u.as<double>(), nullptr,
-                         L.tmp.as<double>(), 1.0, 0, st));
-      HIP_TRY(launch_add_inplace(L.n, L.tmp.as<double>(), L.u.as<double>(), st));
+      const DevCsr& P = L.P_rows;  // u_h = u_h + P u_H in one launch
+      HIP_TRY(launch_csr(CSR_SPMV_ADD, P.n_rows, P.nnz, P.max_block_nnz, P.max_row_nnz,
+                         P.rowptr(), P.col(), P.v(), C.u.as<double>(), L.u.as<double>(),
+                         L.u.as<double>(), 1.0, 0, st));
     }
     if (pair_up_ok(s, l)) {                                        // :300, both sweeps
       Level& F = s->lv[l - 1];
@@ -2097,6 +2096,7 @@ amg_hip_status amg_hip_slab_setup(amg_hip_solver* s, int32_t rank, int32_t world
   HIP_TRY(hipStreamSynchronize(s->stream));
   Slab& sb = s->slab;
   sb.reset_graphs();
+  sb.levels = 0;  // configured again only when everything below succeeds
   const Level& L0 = s->lv[0];
   const int64_t m0 = L0.A_rows.patch_m;
   sb.lines = (L0.n + m0 - 1) / m0;
@@ -2122,8 +2122,11 @@ amg_hip_status amg_hip_slab_setup(amg_hip_solver* s, int32_t rank, int32_t world
   // in-place all-gathers need room for world equal blocks
   Level& G = s->lv[k];
   const int64_t mk = m0 >> k;
-  if ((r = grow(G.f, sizeof(double) * (size_t)(sb.chunk * world * mk), s->stream)) != AMG_HIP_OK) return r;
-  if ((r = grow(s->lv[0].u, sizeof(double) * (size_t)(sb.chunk * world * m0), s->stream)) != AMG_HIP_OK) return r;
+  if ((r = grow(G.f, sizeof(double) * (size_t)(sb.chunk * world * mk), s->stream)) != AMG_HIP_OK ||
+      (r = grow(s->lv[0].u, sizeof(double) * (size_t)(sb.chunk * world * m0), s->stream)) != AMG_HIP_OK) {
+    sb.levels = 0;  // not configured: amg_hip_slab_run refuses
+    return r;
+  }
   if (s->graph_ready) {  // the whole-cycle graph holds the old pointers
     (void)hipGraphExecDestroy(s->graph_exec);
     (void)hipGraphDestroy(s->graph);
@@ -2231,9 +2234,8 @@ amg_hip_status amg_hip_level_op(amg_hip_solver* s, int32_t level, int32_t op) {
         HIP_TRY(launch_linear_prolong_add(L.n, C.n, C.u.as<double>(), L.u.as<double>(), st));
       } else {
         const DevCsr& P = L.P_rows;
-        HIP_TRY(launch_csr(CSR_SPMV, P.n_rows, P.nnz, P.max_block_nnz, P.max_row_nnz, P.rowptr(),
-                           P.col(), P.v(), C.u.as<double>(), nullptr, L.tmp.as<double>(), 1.0, 0, st));
-        HIP_TRY(launch_add_inplace(L.n, L.tmp.as<double>(), L.u.as<double>(), st));
+        HIP_TRY(launch_csr(CSR_SPMV_ADD, P.n_rows, P.nnz, P.max_block_nnz, P.max_row_nnz, P.rowptr(),
+                           P.col(), P.v(), C.u.as<double>(), L.u.as<double>(), L.u.as<double>(), 1.0, 0, st));
       }
       return AMG_HIP_OK;
     }
