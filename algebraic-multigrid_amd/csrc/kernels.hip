@@ -2286,7 +2286,7 @@ __global__ __launch_bounds__(1024) void gs_scan_kernel(
   __shared__ double last_u;                  // new value of the row before this chunk
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   scan_stage_tables(tab, wtab, WORDS, rtype, rwords, doff, dval, ntab);
-  for (int i = t; i <= ringmask; i += 1024) ring[i] = 0.0;
+  for (int i = t; i <= ringmask; i += (int)blockDim.x) ring[i] = 0.0;
   if (t == 0) last_u = 0.0;
   __syncthreads();
   const int nchunks = (n + C - 1) / C;
@@ -2412,6 +2412,7 @@ __global__ __launch_bounds__(1024) void gs_scan_kernel(
 // and the serial kernel evaluates  c_k = P_k - sum_e w_e u_new[k + off_e],  q_k = Q  with
 // w_e = a_e / a_kk (x omega), Q = -a_chain / a_kk (x omega) from a per-type LDS table: no code
 // words, no division and at most SCAN_NEW ring reads on the serial path.
+__device__ __forceinline__ double readlane_f64(double v, int lane);  // K-Band section below
 constexpr int SCAN_NEW = 4;  // new-side entries other than the chain, per row type (2-D: 3)
 // per-type table as three LDS arrays: tq[256], tw[256 * SCAN_NEW], toff[256 * SCAN_NEW];
 // thread t < 256 builds the entry of type t from its code words (type 255 / unused: zeros)
@@ -2505,7 +2506,7 @@ __global__ __launch_bounds__(1024) void gs_scan_typed_kernel(
   __shared__ double last_u;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   scan_stage_tables(tab, wtab, WORDS, rtype, rwords, doff, dval, ntab);
-  for (int i = t; i <= ringmask; i += 1024) ring[i] = 0.0;
+  for (int i = t; i <= ringmask; i += (int)blockDim.x) ring[i] = 0.0;
   if (t == 0) last_u = 0.0;
   __syncthreads();
   scan_build_types<WORDS, UN>(tq, tw, toff, tab, wtab, backward, mode, omega);
@@ -2534,6 +2535,42 @@ __global__ __launch_bounds__(1024) void gs_scan_typed_kernel(
   if (active) {
     fetch(0, cur);
     fetch(1, nx1);
+  }
+  if (nwaves == 1) {
+    // A chunk of at most 64 rows (the deep levels: short grid lines) is ONE wave's scan: no
+    // cross-wave combine, no barrier -- the wave's LDS accesses keep their order -- and the
+    // carry travels in a register.  Same products and sums as the general path below.
+    if (wave != 0) return;
+    double carry = 0.0;  // wave-uniform: the last new value of the previous chunk
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      fetch(chunk + 2, nx2);
+      double q = 0.0, c = 0.0;
+      if (cur.live) {
+        const int tb = (int)cur.ty * SCAN_NEW;
+        double rv[SCAN_NEW], wv[SCAN_NEW];
+#pragma unroll
+        for (int e = 0; e < SCAN_NEW; ++e) {
+          wv[e] = tw[tb + e];
+          rv[e] = ring[(cur.k + toff[tb + e]) & ringmask];
+        }
+        c = cur.p;
+#pragma unroll
+        for (int e = 0; e < SCAN_NEW; ++e) c -= wv[e] * rv[e];
+        q = tq[cur.ty];
+      }
+      double Q = q, Cc = c;
+      affine_scan_wave(Q, Cc);
+      const double unew = Cc + Q * carry;
+      if (cur.live) {
+        ring[cur.k & ringmask] = unew;
+        u[cur.k] = unew;
+      }
+      const int last_t = (chunk * C + C <= n ? C : n - chunk * C) - 1;
+      carry = readlane_f64(unew, last_t);
+      cur = nx1;
+      nx1 = nx2;
+    }
+    return;
   }
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     double Q = 1.0, Cc = 0.0;
@@ -2605,14 +2642,18 @@ static hipError_t launch_gs_scan_wu(int64_t n, const DictRef& D, const double* b
     hipLaunchKernelGGL((gs_scan_prep_typed_kernel<WORDS, UN>), dim3((unsigned)((n + 255) / 256)), dim3(256),
                        0, st, (int)n, D.rtype, D.rwords, D.doff, D.dval, D.ntab, b, u, backward, mode, omega,
                        s_old);
-    hipLaunchKernelGGL((gs_scan_typed_kernel<WORDS, UN>), dim3(1), dim3(1024), (size_t)ring * 8, st, (int)n,
+    // as many waves as the chunk has rows (at least the four that stage the tables): the three
+    // barriers per chunk cost what the waves they hold up cost, and a deep level's chunk is short
+    const int nt = std::max(256, (C + 63) / 64 * 64);
+    hipLaunchKernelGGL((gs_scan_typed_kernel<WORDS, UN>), dim3(1), dim3(nt), (size_t)ring * 8, st, (int)n,
                        D.rtype, D.rwords, D.doff, D.dval, D.ntab, u, s_old, backward, mode, omega, C,
                        ring - 1);
     return hipGetLastError();
   }
   hipLaunchKernelGGL((gs_scan_prep_kernel<WORDS, UN>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                      (int)n, D.codes, D.rtype, D.rwords, D.doff, D.dval, D.ntab, u, backward, s_old);
-  hipLaunchKernelGGL((gs_scan_kernel<WORDS, UN>), dim3(1), dim3(1024), (size_t)ring * 8, st, (int)n,
+  const int nt = std::max(256, (C + 63) / 64 * 64);
+  hipLaunchKernelGGL((gs_scan_kernel<WORDS, UN>), dim3(1), dim3(nt), (size_t)ring * 8, st, (int)n,
                      D.codes, D.rtype, D.rwords, D.doff, D.dval, D.ntab, b, u, s_old, backward, mode,
                      omega, C, ring - 1);
   return hipGetLastError();
