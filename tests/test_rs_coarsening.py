@@ -130,3 +130,32 @@ def test_c_abi_argument_validation_without_device():
     o.host_only = 1
     assert lib.amg_hip_create_rs(4, None, None, None, None, 3, 0.25, 10, C.byref(o), C.byref(h)) == amg.EINVAL
     assert lib.amg_hip_create_rs(4, None, None, None, None, 3, 0.25, 10, C.byref(o), None) == amg.EINVAL
+
+
+def test_sign_convention_and_nonsymmetric_input(oracle):
+    """Couplings are measured against the sign of the diagonal: the reference's negative definite
+    operator and its negation give the same splitting and the same interpolation weights.  A
+    row-scaled (non-symmetric) matrix still yields the product == twin hierarchy."""
+    import amg_ctypes as amg
+    n = 20
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    P1, c1 = oracle.ruge_stueben_P(A, 0.25)
+    An = oracle.CSC(A.rows, A.cols, A.colptr, A.rowind, -A.val)
+    P2, c2 = oracle.ruge_stueben_P(An, 0.25)
+    assert np.array_equal(c1, c2) and np.array_equal(P1.rowind, P2.rowind) and np.array_equal(P1.val, P2.val)
+    # row scaling D A (D diagonal, positive): strength ratios per row unchanged -> same C/F split
+    S = A.to_scipy().tocsr()
+    d = 1.0 + 0.5 * np.arange(S.shape[0]) / S.shape[0]
+    import scipy.sparse as sp
+    M = (sp.diags(d) @ S).tocsc()
+    M.sort_indices()
+    As = oracle.CSC(A.rows, A.cols, M.indptr, M.indices, M.data)
+    Ps = oracle.ruge_stueben_hierarchy(As, 6, 0.25, 30)
+    P3, c3 = oracle.ruge_stueben_P(As, 0.25)
+    assert np.array_equal(c3, c1)
+    mg = amg.Multigrid.ruge_stueben(As.colptr, As.rowind, As.val, b, 6, 0.25, 30, host_only=True)
+    assert mg.n_levels == len(Ps) + 1
+    for l, P in enumerate(Ps):
+        cp, ri, v = mg.get_transfer(l, "P")
+        assert np.array_equal(cp, P.colptr) and np.array_equal(ri, P.rowind) and np.array_equal(v, P.val)
+    mg.close()
