@@ -39,7 +39,7 @@ class Options(C.Structure):
                 ("fast_coarse_solve", C.c_int32), ("host_galerkin", C.c_int32),
                 ("keep_residual", C.c_int32), ("exact_coarse_solve", C.c_int32),
                 ("exact_gs", C.c_int32),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("window", C.c_int32), ("reserved0", C.c_int32)]
 
 
 SLAB_MAX_LEVELS = 8
@@ -127,6 +127,11 @@ _SIGS = {
     "amg_hip_slab_plan": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(SlabInfo)]),
     "amg_hip_slab_setup": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(SlabInfo)]),
     "amg_hip_slab_run": (C.c_int, [C.c_void_p, C.c_int32]),
+    "amg_hip_create_poisson_window": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                                C.POINTER(Options), C.POINTER(C.c_void_p)]),
+    "amg_hip_window_setup": (C.c_int, [C.c_void_p, _i64p, _i64p, _i64p, _i64p]),
+    "amg_hip_window_run": (C.c_int, [C.c_void_p, C.c_int32]),
+    "amg_hip_vec_dev_ptr": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), _i64p]),
     "amg_hip_level_layout": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "amg_hip_get_colors": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p]),
     "amg_hip_level_op": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
@@ -438,6 +443,43 @@ class Multigrid:
         _chk(st)
         self._h = h
         return self
+
+    @classmethod
+    def poisson_window(cls, n, unit_begin, unit_end, n_levels, dim=2, smoother=SM_JACOBI, smoother_iters=2,
+                       omega=0.6, device=-1, use_graph=True, layout=None, no_fusion=False, stream=None,
+                       host_only=False):
+        """One rank's WINDOW of a sharded Grid::laplacian(n) hierarchy (amg_hip_create_poisson_window):
+        units [unit_begin, unit_end) of the slowest axis, n_levels - 1 distributed levels; runs by
+        parts (window_run)."""
+        self = cls.__new__(cls)
+        self.tolerance, self.every, self.n_iters = 1e-9, 10, 100
+        o = cls._options(smoother, smoother_iters, omega, device, use_graph, True, layout, host_only, False,
+                         no_fusion, False, stream, False, False, False, False, False)
+        o.window = 1
+        h = C.c_void_p()
+        st = lib().amg_hip_create_poisson_window(dim, n, int(unit_begin), int(unit_end), n_levels,
+                                                 C.byref(o), C.byref(h))
+        if st == EINVAL:
+            raise ValueError(lib().amg_hip_last_error().decode())
+        _chk(st)
+        self._h = h
+        return self
+
+    def window_setup(self, down_lo=None, down_hi=None, up_lo=None, up_hi=None):
+        if down_lo is None:
+            _chk(lib().amg_hip_window_setup(self._h, None, None, None, None))
+            return
+        arrs = [np.ascontiguousarray(a, dtype=np.int64) for a in (down_lo, down_hi, up_lo, up_hi)]
+        _chk(lib().amg_hip_window_setup(self._h, *[a.ctypes.data_as(_i64p) for a in arrs]))
+
+    def window_run(self, part):
+        _chk(lib().amg_hip_window_run(self._h, int(part)))
+
+    def vec_dev_ptr(self, level, which):
+        """(device pointer, n) of a level vector; which: "u", "f" or "r"."""
+        p, n = C.c_void_p(), C.c_int64(0)
+        _chk(lib().amg_hip_vec_dev_ptr(self._h, level, {"u": 0, "f": 1, "r": 2}[which], C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
 
     def close(self):
         if getattr(self, "_h", None):

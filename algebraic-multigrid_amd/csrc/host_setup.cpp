@@ -827,18 +827,22 @@ void build_color_perm(const Sparse& M, const std::vector<int32_t>& color, int32_
 }
 
 // ---------------------------------------------------------------- grid.hpp ---
-Sparse laplacian(int dim, int64_t n) {
+Sparse laplacian(int dim, int64_t n, int64_t n_last) {
   // grid.hpp:31,50-75,88-98.  D = tridiag(1,-2,1)/(h*h) with h = 2/(n+1);
   // A = sum over axes of I (x) .. D .. (x) I.  Diagonal = D_ii added once per
   // axis; every off-diagonal appears in exactly one Kronecker term.
+  // n_last >= 1: only n_last units (grid lines in 2-D, x-y planes in 3-D) of the slowest axis,
+  // i.e. the principal submatrix of a block of whole units -- the WINDOW of a sharded solver
+  // (amg_hip_create_poisson_window); h stays that of the n^dim problem.
   const double h = 2.0 / (double)(n + 1);
   const double hh = h * h;
   const double off = 1.0 / hh;
   const double dg = -2.0 / hh;
   double diag = dg + dg;
   if (dim == 3) diag = diag + dg;
-  int64_t N = n * n;
-  if (dim == 3) N *= n;
+  if (n_last < 1) n_last = n;
+  const int64_t ext[3] = {n, dim == 2 ? n_last : n, dim == 3 ? n_last : 1};
+  const int64_t N = ext[0] * ext[1] * ext[2];
   const int64_t strides[3] = {1, n, n * n};
   Sparse A;
   A.n_outer = A.n_inner = N;
@@ -847,7 +851,7 @@ Sparse laplacian(int dim, int64_t n) {
   A.idx.reserve((size_t)N * (2 * dim + 1));
   A.val.reserve((size_t)N * (2 * dim + 1));
   for (int64_t c = 0; c < N; ++c) {
-    int64_t coord[3] = {c % n, (c / n) % n, c / (n * n)};
+    int64_t coord[3] = {c % n, dim == 2 ? c / n : (c / n) % n, c / (n * n)};
     for (int a = dim - 1; a >= 0; --a)  // lower neighbours, ascending index
       if (coord[a] > 0) {
         A.idx.push_back((int32_t)(c - strides[a]));
@@ -856,7 +860,7 @@ Sparse laplacian(int dim, int64_t n) {
     A.idx.push_back((int32_t)c);
     A.val.push_back(diag);
     for (int a = 0; a < dim; ++a)
-      if (coord[a] + 1 < n) {
+      if (coord[a] + 1 < ext[a]) {
         A.idx.push_back((int32_t)(c + strides[a]));
         A.val.push_back(off);
       }

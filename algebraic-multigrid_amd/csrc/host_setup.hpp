@@ -211,7 +211,7 @@ void build_color_perm(const Sparse& rows_as, const std::vector<int32_t>& color,
                       int32_t n_colors, ColorPerm* out);
 
 // ---- Grid<double> (grid.hpp) ------------------------------------------------
-Sparse laplacian(int dim, int64_t n);       // CSC (== CSR, symmetric)
+Sparse laplacian(int dim, int64_t n, int64_t n_last = -1);  // CSC (== CSR, symmetric); n_last: units of the slowest axis (window)
 void rhs(int dim, int64_t n, double* b);
 void rhs_range(int dim, int64_t n, double* b, int64_t dof0, int64_t dof1);  // entries [dof0, dof1)
 

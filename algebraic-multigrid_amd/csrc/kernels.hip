@@ -3505,38 +3505,42 @@ hipError_t launch_galerkin_rap(bool fill, int64_t n_h, int64_t n_H, const int32_
 // A = sum over axes of I (x) .. D .. (x) I, D = tridiag(1, -2, 1) / h^2: row c holds its lower
 // neighbours (axes dim-1 .. 0), the diagonal, its upper neighbours (axes 0 .. dim-1) --
 // ascending columns, the order host_setup.cpp: laplacian() produces.
-__global__ __launch_bounds__(256) void lap_count_kernel(int dim, int64_t n, int64_t N,
+// n_last: units (grid lines in 2-D, x-y planes in 3-D) of the slowest axis -- n for the whole
+// problem, fewer for the window of a sharded solver (host_setup.cpp: laplacian).
+__global__ __launch_bounds__(256) void lap_count_kernel(int dim, int64_t n, int64_t n_last, int64_t N,
                                                         int32_t* __restrict__ cnt) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= N) return;
-  const int64_t co[3] = {c % n, (c / n) % n, c / (n * n)};
+  const int64_t co[3] = {c % n, dim == 2 ? c / n : (c / n) % n, c / (n * n)};
+  const int64_t ext[3] = {n, dim == 2 ? n_last : n, n_last};
   int k = 1;
-  for (int a = 0; a < dim; ++a) k += (co[a] > 0) + (co[a] + 1 < n);
+  for (int a = 0; a < dim; ++a) k += (co[a] > 0) + (co[a] + 1 < ext[a]);
   cnt[c] = k;
 }
-__global__ __launch_bounds__(256) void lap_fill_kernel(int dim, int64_t n, int64_t N,
+__global__ __launch_bounds__(256) void lap_fill_kernel(int dim, int64_t n, int64_t n_last, int64_t N,
                                                        const int32_t* __restrict__ rowptr,
                                                        int32_t* __restrict__ col,
                                                        double* __restrict__ val, double off,
                                                        double diag) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= N) return;
-  const int64_t co[3] = {c % n, (c / n) % n, c / (n * n)};
+  const int64_t co[3] = {c % n, dim == 2 ? c / n : (c / n) % n, c / (n * n)};
+  const int64_t ext[3] = {n, dim == 2 ? n_last : n, n_last};
   const int64_t st[3] = {1, n, n * n};
   int64_t p = rowptr[c];
   for (int a = dim - 1; a >= 0; --a)
     if (co[a] > 0) { col[p] = (int32_t)(c - st[a]); val[p] = off; ++p; }
   col[p] = (int32_t)c; val[p] = diag; ++p;
   for (int a = 0; a < dim; ++a)
-    if (co[a] + 1 < n) { col[p] = (int32_t)(c + st[a]); val[p] = off; ++p; }
+    if (co[a] + 1 < ext[a]) { col[p] = (int32_t)(c + st[a]); val[p] = off; ++p; }
 }
-hipError_t launch_laplacian_count(int dim, int64_t n, int64_t N, int32_t* cnt, hipStream_t st) {
-  hipLaunchKernelGGL(lap_count_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dim, n, N, cnt);
+hipError_t launch_laplacian_count(int dim, int64_t n, int64_t n_last, int64_t N, int32_t* cnt, hipStream_t st) {
+  hipLaunchKernelGGL(lap_count_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dim, n, n_last, N, cnt);
   return hipGetLastError();
 }
-hipError_t launch_laplacian_fill(int dim, int64_t n, int64_t N, const int32_t* rowptr, int32_t* col,
+hipError_t launch_laplacian_fill(int dim, int64_t n, int64_t n_last, int64_t N, const int32_t* rowptr, int32_t* col,
                                  double* val, double off, double diag, hipStream_t st) {
-  hipLaunchKernelGGL(lap_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dim, n, N,
+  hipLaunchKernelGGL(lap_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dim, n, n_last, N,
                      rowptr, col, val, off, diag);
   return hipGetLastError();
 }

@@ -265,8 +265,8 @@ hipError_t launch_galerkin_rap(bool fill, int64_t n_h, int64_t n_H, const int32_
                                const int32_t* orp, int32_t* ocol, double* oval, hipStream_t st);
 
 // K-Setup: Grid generators and the dictionary encoder on the device (kernels.hip)
-hipError_t launch_laplacian_count(int dim, int64_t n, int64_t N, int32_t* cnt, hipStream_t st);
-hipError_t launch_laplacian_fill(int dim, int64_t n, int64_t N, const int32_t* rowptr, int32_t* col,
+hipError_t launch_laplacian_count(int dim, int64_t n, int64_t n_last, int64_t N, int32_t* cnt, hipStream_t st);
+hipError_t launch_laplacian_fill(int dim, int64_t n, int64_t n_last, int64_t N, const int32_t* rowptr, int32_t* col,
                                  double* val, double off, double diag, hipStream_t st);
 // stats[0] = longest row (exact zeros skipped when prune), stats[1] = 1 when not bitwise
 // symmetric (both zero-initialised by the caller); diag (optional) = a_ii

@@ -849,7 +849,8 @@ bool fuses_resid_restrict(const amg_hip_solver* s, int l) {
 // Levels 0 .. k of a 2+2 true-Jacobi cycle whose matrices are row-typed dictionaries with a
 // 2-D band (the finer level's kernel hands the first sweep of the next one over).
 bool patch_level_ok(const amg_hip_solver* s, int l) {
-  if (l < 0 || l + 2 >= (int)s->lv.size()) return false;  // needs a smoothed coarser level
+  // needs a smoothed coarser level (a window's last level is one: it is smoothed by the tail solver)
+  if (l < 0 || l + (s->opt.window ? 1 : 2) >= (int)s->lv.size()) return false;
   const Level& L = s->lv[l];
   const DevMat& A = L.A_rows;
   if (!(jacobi_fuses_zero(s) && !s->opt.fuse_prolong && s->opt.smoother_iters == 2 && L.symmetric &&
@@ -1112,6 +1113,8 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
     }
   }
   if (!ranged) {                                                   // :287-288
+    if (s->opt.window)
+      return fail(AMG_HIP_EINVAL, "a window solver (opt.window) runs by parts: amg_hip_window_run");
     Level& C = s->lv[nl - 1];
     HIP_TRY(launch_coarse(s->coarse, C.f.as<double>(), C.tmp.as<double>(), C.u.as<double>(), st));
   }
@@ -1529,7 +1532,7 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
   HIP_TRY(hipMemcpy(s->lv[0].f.p, b, sizeof(double) * n, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s->lv[0].r.p, b, sizeof(double) * n, hipMemcpyHostToDevice));  // b - A*0
   // ---- coarsest factor (multigrid.hpp:240-243) ----
-  {
+  if (!s->opt.window) {
     const int want = s->opt.fast_coarse_solve ? 1 : (s->opt.exact_coarse_solve ? -1 : 0);
     amg_hip_status r = upload_coarse(s->lv[n_levels - 1].A_csc, want, &s->coarse);
     if (r != AMG_HIP_OK) return r;
@@ -1679,7 +1682,7 @@ hipError_t device_dict_encode(const DevCsr& A, bool prune, int maxlen, DevMat* D
   return hipSuccess;
 }
 
-void rhs_threads(int dim, int64_t n, double* b, int nt);  // below
+void rhs_threads(int dim, int64_t n, double* b, int nt, int64_t d0 = 0, int64_t d1 = -1);  // below
 
 // AMG::Multigrid's constructor (multigrid.hpp:151-244) for A = Grid::laplacian(n), b =
 // Grid::rhs(n) without host matrices: generator, Galerkin chain, dictionary encoder, diagonal
@@ -1687,14 +1690,18 @@ void rhs_threads(int dim, int64_t n, double* b, int nt);  // below
 // the bits are libm's, like the reference's) and the coarsest operator (factored on the host)
 // cross PCIe.  *unsupported = true: the options need host structures (exact lexicographic
 // schedules, multicolouring, non-dictionary layouts): the caller takes the host path instead.
+// [unit0, unit1): the grid lines (2-D) / x-y planes (3-D) of a window solver, else unit1 < 0.
 amg_hip_status build_poisson_device(int dim, int64_t n, int32_t n_levels, const amg_hip_options* opts,
-                                    amg_hip_solver** out, bool* unsupported) {
+                                    amg_hip_solver** out, bool* unsupported, int64_t unit0 = 0,
+                                    int64_t unit1 = -1) {
   *unsupported = true;
   amg_hip_options o;
   if (opts) o = *opts;
   else amg_hip_default_options(&o);
-  int64_t N = n * n;
-  if (dim == 3) N *= n;
+  if (unit1 < 0) { unit0 = 0; unit1 = n; }
+  const int64_t n_last = unit1 - unit0;
+  const int64_t unit_rows = dim == 3 ? n * n : n;
+  const int64_t N = unit_rows * n_last;
   const bool lex = o.smoother <= AMG_HIP_SM_SOR;
   if (o.host_only || o.host_galerkin || !o.stencil_transfers || o.fuse_prolong ||
       (o.layout != AMG_HIP_LAYOUT_AUTO && o.layout != AMG_HIP_LAYOUT_DICT) ||
@@ -1732,7 +1739,7 @@ amg_hip_status build_poisson_device(int dim, int64_t n, int32_t n_levels, const 
   };
   // b on the host threads while the device builds the hierarchy
   std::vector<double> b((size_t)N);
-  std::thread rhs_thread([&] { rhs_threads(dim, n, b.data(), host_threads()); });
+  std::thread rhs_thread([&] { rhs_threads(dim, n, b.data(), host_threads(), unit0 * unit_rows, unit1 * unit_rows); });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{rhs_thread};
   // A_0 (grid.hpp:88-98)
   DevCsr cur;
@@ -1741,7 +1748,7 @@ amg_hip_status build_poisson_device(int dim, int64_t n, int32_t n_levels, const 
     HIP_TRY(cnt.alloc(sizeof(int32_t) * (N + 1)));
     HIP_TRY(bsum.alloc(sizeof(int64_t) * ((N + 1023) / 1024 + 1)));
     HIP_TRY(total.alloc(sizeof(int64_t)));
-    HIP_TRY(launch_laplacian_count(dim, n, N, cnt.as<int32_t>(), nullptr));
+    HIP_TRY(launch_laplacian_count(dim, n, n_last, N, cnt.as<int32_t>(), nullptr));
     HIP_TRY(cur.ptr.alloc(sizeof(int32_t) * (N + 1)));
     HIP_TRY(launch_exclusive_scan(N, cnt.as<int32_t>(), cur.ptr.as<int32_t>(), bsum.as<int64_t>(),
                                   total.as<int64_t>(), nullptr));
@@ -1754,7 +1761,7 @@ amg_hip_status build_poisson_device(int dim, int64_t n, int32_t n_levels, const 
     const double off = 1.0 / hh, dg = -2.0 / hh;
     double diag = dg + dg;
     if (dim == 3) diag = diag + dg;
-    HIP_TRY(launch_laplacian_fill(dim, n, N, cur.ptr.as<int32_t>(), cur.idx.as<int32_t>(),
+    HIP_TRY(launch_laplacian_fill(dim, n, n_last, N, cur.ptr.as<int32_t>(), cur.idx.as<int32_t>(),
                                   cur.val.as<double>(), off, diag, nullptr));
     cur.n_rows = cur.n_cols = N;
     cur.nnz = nnz;
@@ -1862,7 +1869,7 @@ amg_hip_status build_poisson_device(int dim, int64_t n, int32_t n_levels, const 
   HIP_TRY(hipMemcpy(s->lv[0].f.p, b.data(), sizeof(double) * N, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s->lv[0].r.p, b.data(), sizeof(double) * N, hipMemcpyHostToDevice));  // b - A*0
   lap("rhs");
-  {
+  if (!o.window) {
     const int want = o.fast_coarse_solve ? 1 : (o.exact_coarse_solve ? -1 : 0);
     HIP_TRY(s->lv[n_levels - 1].ensure_host_matrix());
     amg_hip_status r = upload_coarse(s->lv[n_levels - 1].A_csc, want, &s->coarse);
@@ -1883,17 +1890,20 @@ struct Scoped {
   ~Scoped() { if (st) (void)hipStreamDestroy(st); }
 };
 
-// Grid::rhs on several host threads (the values are libm's exp(), as in the reference)
-void rhs_threads(int dim, int64_t n, double* b, int nt) {
+// Grid::rhs on several host threads (the values are libm's exp(), as in the reference);
+// entries [d0, d1) of the right-hand side into b[0 .. d1 - d0) (d1 < 0: all)
+void rhs_threads(int dim, int64_t n, double* b, int nt, int64_t d0, int64_t d1) {
   int64_t N = n * n;
   if (dim == 3) N *= n;
-  if (nt <= 1 || N < (1 << 18)) {
-    rhs(dim, n, b);
+  if (d1 < 0) { d0 = 0; d1 = N; }
+  const int64_t M = d1 - d0;
+  if (nt <= 1 || M < (1 << 18)) {
+    rhs_range(dim, n, b - d0, d0, d1);
     return;
   }
   std::vector<std::thread> th;
   for (int t = 0; t < nt; ++t)
-    th.emplace_back([=] { rhs_range(dim, n, b, N * t / nt, N * (t + 1) / nt); });
+    th.emplace_back([=] { rhs_range(dim, n, b - d0, d0 + M * t / nt, d0 + M * (t + 1) / nt); });
   for (auto& x : th) x.join();
 }
 
@@ -1926,6 +1936,8 @@ void amg_hip_default_options(amg_hip_options* o) {
   o->fuse_prolong = 0;
   o->fast_coarse_solve = 0;
   o->stream = nullptr;
+  o->window = 0;
+  o->reserved0 = 0;
 }
 
 void amg_hip_set_index16(int32_t on) { g_index16 = on ? 1 : 0; }
@@ -1990,6 +2002,32 @@ amg_hip_status amg_hip_create_poisson(int32_t dim, int64_t n, int32_t n_levels,
   std::vector<double> b((size_t)A.n_outer);
   rhs_threads(dim, n, b.data(), host_threads());
   return amg_hip_create(A.n_outer, A.ptr.data(), A.idx.data(), A.val.data(), b.data(), n_levels, opts, out);
+}
+
+amg_hip_status amg_hip_create_poisson_window(int32_t dim, int64_t n, int64_t unit_begin, int64_t unit_end,
+                                             int32_t n_levels, const amg_hip_options* opts,
+                                             amg_hip_solver** out) {
+  if (!out) return fail(AMG_HIP_EINVAL, "out handle pointer is null");
+  *out = nullptr;
+  if ((dim != 2 && dim != 3) || n < 1) return fail(AMG_HIP_EINVAL, "dim must be 2 or 3 and n >= 1");
+  if (unit_begin < 0 || unit_end > n || unit_end - unit_begin < 1)
+    return fail(AMG_HIP_EINVAL, "window units must satisfy 0 <= unit_begin < unit_end <= n");
+  const int64_t unit_rows = dim == 3 ? n * n : n;
+  if ((unit_begin * unit_rows) & 1)
+    return fail(AMG_HIP_EINVAL, "a window must begin at an even flat index (coarse dof j <-> fine dof 2j+1, multigrid.hpp:127-130)");
+  if (n_levels < 2) return fail(AMG_HIP_EINVAL, "a window solver needs at least one distributed level (n_levels >= 2)");
+  amg_hip_options o;
+  if (opts) o = *opts;
+  else amg_hip_default_options(&o);
+  o.window = 1;
+  bool unsupported = true;
+  amg_hip_status r = build_poisson_device(dim, n, n_levels, &o, out, &unsupported, unit_begin, unit_end);
+  if (r != AMG_HIP_OK || !unsupported) return r;
+  // options that need host structures (multicolouring, ...): generate the window on the host
+  Sparse A = laplacian(dim, n, unit_end - unit_begin);
+  std::vector<double> b((size_t)A.n_outer);
+  rhs_threads(dim, n, b.data(), host_threads(), unit_begin * unit_rows, unit_end * unit_rows);
+  return amg_hip_create(A.n_outer, A.ptr.data(), A.idx.data(), A.val.data(), b.data(), n_levels, &o, out);
 }
 
 void amg_hip_destroy(amg_hip_solver* s) {
@@ -2083,6 +2121,7 @@ amg_hip_status amg_hip_slab_setup(amg_hip_solver* s, int32_t rank, int32_t world
                                   int32_t max_levels, amg_hip_slab_info* info) {
   if (!s || !info || world < 1 || rank < 0 || rank >= world)
     return fail(AMG_HIP_EINVAL, "amg_hip_slab_setup: bad argument");
+  if (s->opt.window) return fail(AMG_HIP_EINVAL, "amg_hip_slab_setup: a window solver is cut already (amg_hip_window_setup)");
   amg_hip_status r = set_device(s);
   if (r != AMG_HIP_OK) return r;
   int k = 0;
@@ -2166,6 +2205,58 @@ amg_hip_status amg_hip_slab_run(amg_hip_solver* s, int32_t part) {
     HIP_TRY(hipGraphInstantiate(&sb.exec[gi], g, nullptr, nullptr, 0));
   }
   HIP_TRY(hipGraphLaunch(sb.exec[gi], s->stream));
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_window_setup(amg_hip_solver* s, const int64_t* down_lo, const int64_t* down_hi,
+                                    const int64_t* up_lo, const int64_t* up_hi) {
+  if (!s) return fail(AMG_HIP_EINVAL, "null solver");
+  if (!s->opt.window) return fail(AMG_HIP_EINVAL, "amg_hip_window_setup: not a window solver (opt.window)");
+  if ((down_lo || down_hi || up_lo || up_hi) && !(down_lo && down_hi && up_lo && up_hi))
+    return fail(AMG_HIP_EINVAL, "amg_hip_window_setup: give all four range arrays or none");
+  amg_hip_status r = set_device(s);
+  if (r != AMG_HIP_OK) return r;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  const int k = (int)s->lv.size() - 1;
+  Slab& sb = s->slab;
+  sb.reset_graphs();
+  sb.levels = k;
+  sb.rank = 0;
+  sb.world = 1;
+  sb.down_lo.assign(k, 0);
+  sb.down_hi.assign(k, -1);  // -1: every line
+  sb.up_lo.assign(k, 0);
+  sb.up_hi.assign(k, -1);
+  if (down_lo)
+    for (int l = 0; l < k; ++l) {
+      if (down_lo[l] < 0 || up_lo[l] < 0 || down_hi[l] < down_lo[l] || up_hi[l] < up_lo[l])
+        return fail(AMG_HIP_EINVAL, "amg_hip_window_setup: bad line range");
+      sb.down_lo[l] = down_lo[l];
+      sb.down_hi[l] = down_hi[l];
+      sb.up_lo[l] = up_lo[l];
+      sb.up_hi[l] = up_hi[l];
+    }
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_window_run(amg_hip_solver* s, int32_t part) {
+  if (!s || (part != CYCLE_SLAB_DOWN && part != CYCLE_SLAB_UP))
+    return fail(AMG_HIP_EINVAL, "amg_hip_window_run: part is 1 (down-legs) or 3 (up-legs)");
+  if (!s->opt.window) return fail(AMG_HIP_EINVAL, "amg_hip_window_run: not a window solver (opt.window)");
+  if (s->slab.levels < 1) {
+    amg_hip_status r = amg_hip_window_setup(s, nullptr, nullptr, nullptr, nullptr);
+    if (r != AMG_HIP_OK) return r;
+  }
+  return amg_hip_slab_run(s, part);
+}
+
+amg_hip_status amg_hip_vec_dev_ptr(amg_hip_solver* s, int32_t level, int32_t which, void** ptr, int64_t* n) {
+  if (!s || !ptr || level < 0 || level >= (int32_t)s->lv.size() || which < 0 || which > 2)
+    return fail(AMG_HIP_EINVAL, "bad argument");
+  if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "solver was created with host_only = 1: no device state");
+  Level& L = s->lv[level];
+  *ptr = which == 0 ? L.u.p : (which == 1 ? L.f.p : L.r.p);
+  if (n) *n = L.n;
   return AMG_HIP_OK;
 }
 

@@ -127,6 +127,12 @@ typedef struct {
                               orders its device work on a stream (torch's current
                               stream in the multi-GPU driver) passes it here so that
                               no host synchronisation is needed between the two.   */
+  int32_t window;          /* 1: the solver is one rank's WINDOW of a sharded hierarchy
+                              ("window sharding" below): its coarsest level is the level
+                              the ranks all-gather, so it is neither factored nor solved
+                              here; amg_hip_vcycle / solve / apply / pcg are refused and
+                              the cycle runs by parts (amg_hip_window_run).  Default 0. */
+  int32_t reserved0;       /* 0 */
 } amg_hip_options;
 
 typedef struct amg_hip_solver amg_hip_solver; /* opaque; owns device memory    */
@@ -279,6 +285,46 @@ amg_hip_status amg_hip_slab_setup(amg_hip_solver* s, int32_t rank, int32_t world
 /* part 1: down-legs of the slab levels; 2: the replicated rest of the cycle (from the gathered
  * rhs); 3: up-legs of the slab levels.  Asynchronous on the solver's stream (one hipGraph each). */
 amg_hip_status amg_hip_slab_run(amg_hip_solver* s, int32_t part);
+
+/* ---- window sharding: row blocks with sharded STORAGE and SETUP ------------
+ * The reference's flat-index coarsening (multigrid.hpp:127-130, interpolator.hpp:116-129)
+ * coarsens the fast axis only, so the grid lines (2-D) / x-y planes (3-D) -- "units" -- of every
+ * level coincide and a block of whole units is a consistent cut of the whole hierarchy.  Rank g
+ * creates an ORDINARY solver on the principal submatrix of its WINDOW of units [unit_begin,
+ * unit_end) = its owned units plus `halo` units either side (A = the rows and columns of
+ * Grid::laplacian(n) in the window, b = the window of Grid::rhs(n); grid.hpp:88-140): because
+ * the window starts at an even flat index, coarse dof j of the window is coarse dof j + offset
+ * of the whole problem, the window's LinearInterpolator is the window of the global one, and
+ * every Galerkin row R (A P) (multigrid.hpp:219-223) whose fine rows lie two units inside the
+ * window has the same entries, summed in the same order, as the global row -- bit-identical.
+ * Nothing of the global problem is ever assembled on a rank above the gathered level.
+ * One V-cycle (multigrid.hpp:263-305) on `k` distributed levels:
+ *   1. halo: `halo` units of the level-0 solution from each neighbour (their owned units);
+ *   2. amg_hip_window_run(s, 1): the down-legs of levels 0..k-1 over the window, whatever the
+ *      smoother (each sweep / colour stage / residual / transfer makes one more unit at either
+ *      end of the window stale; the halo depth is chosen so that the owned units of f_k and
+ *      what the up-legs need of u_l stay valid: window_vcycle.py: WindowPlan);
+ *   3. all-gather of the owned units of f_k; the levels >= k (their own solver, built from the
+ *      all-gathered rows of A_k) run replicated, coarse solve included;
+ *   4. the window of u_k goes back into level k of the window solver;
+ *      amg_hip_window_run(s, 3): the up-legs of levels k-1..0.
+ * Per-row arithmetic is the single-GPU kernels', so the owned units of the result equal the
+ * single-GPU cycle bit for bit (tests/test_window_gloo.py, tests/test_gpu_window.py).
+ * amg_hip_create_poisson_window: options as amg_hip_create_poisson; `n_levels` = k + 1 (level k
+ * is only a container for f_k / u_k: opts->window is forced to 1).                         */
+amg_hip_status amg_hip_create_poisson_window(int32_t dim, int64_t n, int64_t unit_begin,
+                                             int64_t unit_end, int32_t n_levels,
+                                             const amg_hip_options* opts, amg_hip_solver** out);
+/* Line ranges (window-local grid lines) for the K-Patch legs of the distributed levels, or
+ * NULL arrays: every leg runs over the whole window.  k = amg_hip_n_levels(s) - 1.           */
+amg_hip_status amg_hip_window_setup(amg_hip_solver* s, const int64_t* down_lo,
+                                    const int64_t* down_hi, const int64_t* up_lo,
+                                    const int64_t* up_hi);
+/* part 1: down-legs (u_0 .. f_k), part 3: up-legs (u_k .. u_0); one hipGraph each.           */
+amg_hip_status amg_hip_window_run(amg_hip_solver* s, int32_t part);
+/* Device pointer of a level vector (which as in amg_hip_get_vec) for zero-copy exchanges. */
+amg_hip_status amg_hip_vec_dev_ptr(amg_hip_solver* s, int32_t level, int32_t which, void** ptr,
+                                   int64_t* n);
 
 /* Multigrid::solve(), multigrid.hpp:311-337: while (iter < n_iters && error >
  * tol) { vcycle(); if (++iter % every == 0) error = rss }.  error starts at 100.
