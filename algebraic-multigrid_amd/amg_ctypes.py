@@ -136,6 +136,7 @@ _SIGS = {
     "amg_hip_get_colors": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p]),
     "amg_hip_level_op": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "amg_hip_cycle_bytes": (C.c_int, [C.c_void_p, _f64p, _f64p]),
+    "amg_hip_cycle_must_move": (C.c_int, [C.c_void_p, C.c_int32, _f64p]),
     "amg_hip_profile_fine_sweep": (C.c_int, [C.c_void_p, C.c_int32, _f64p, _f64p]),
     "amg_hip_smooth": (C.c_int, [C.c_int32, C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p,
                                  C.c_double, C.c_double, C.c_int64, C.c_int64, _i64p, _i32p]),
@@ -566,6 +567,12 @@ class Multigrid:
         a, b = C.c_double(0), C.c_double(0)
         _chk(lib().amg_hip_cycle_bytes(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def cycle_must_move(self, part=0):
+        """bytes the launches of one V-cycle (or of one part of a sharded one) have to move"""
+        b = C.c_double(0)
+        _chk(lib().amg_hip_cycle_must_move(self._h, int(part), C.byref(b)))
+        return b.value
 
     def profile_fine_sweep(self, n_launches):
         """(avg_ms, min_ms, sweeps per launch, kernel name) of the level-0 Jacobi sweep

@@ -803,6 +803,11 @@ struct amg_hip_solver {
   hipGraphExec_t graph_exec = nullptr;
   bool graph_ready = false;
   double cycle_bytes = 0, fine_sweep_bytes = 0;
+  // bytes the launches of one V-cycle HAVE TO move (what each kernel reads and writes once in the
+  // layout it really streams), summed while the cycle is enqueued; [part] as enqueue_vcycle's
+  double must_move[4] = {0, 0, 0, 0};
+  int acct_part = -1;  // -1: not inside enqueue_vcycle
+  void acct(double bytes) { if (acct_part >= 0) must_move[acct_part] += bytes; }
   Slab slab;
 
   ~amg_hip_solver() {
@@ -814,6 +819,15 @@ struct amg_hip_solver {
 };
 
 namespace {
+
+void layout_of(const DevMat& A, int32_t* layout, int64_t* matrix_stream_bytes);  // below
+// matrix stream of one pass over a level matrix in its device layout (dictionary: 1 B row type per
+// row + tables; SELL / CSR: indices + values), the figure amg_hip_level_layout reports
+double mat_bytes(const DevMat& A) {
+  int64_t b = 0;
+  layout_of(A, nullptr, &b);
+  return (double)b;
+}
 
 // ---- smoother on one level --------------------------------------------------
 amg_hip_status enqueue_multicolor(amg_hip_solver* s, Level& L, hipStream_t st);
@@ -904,6 +918,9 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
   const int iters = s->opt.smoother_iters;
   switch (s->opt.smoother) {
     case AMG_HIP_SM_SPGS:
+      // forward + backward sweep: matrix, f, u in, u out each (the scan form's pre-pass also
+      // writes and re-reads one number per row: + 16 n)
+      s->acct(iters * 2.0 * (mat_bytes(L.A_rows) + 24.0 * L.n + (L.scan_C > 0 ? 16.0 * L.n : 0.0)));
       for (int it = 0; it < iters; ++it) {
         if (L.scan_C > 0) {  // line-scan form (kernels.hip: K-GS-scan)
           const DictRef D = L.A_rows.dict_ref();
@@ -920,6 +937,7 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
     case AMG_HIP_SM_REF_JACOBI:
     case AMG_HIP_SM_SOR: {
       const int mode = s->opt.smoother == AMG_HIP_SM_SOR ? 2 : 1;
+      s->acct(iters * (mat_bytes(L.A_rows) + 24.0 * L.n + (L.scan_C > 0 ? 16.0 * L.n : 0.0)));
       for (int it = 0; it < iters; ++it) {
         if (L.scan_C > 0) {
           HIP_TRY(launch_gs_scan(L.n, L.A_rows.dict_ref(), L.f.as<double>(), L.u.as<double>(),
@@ -942,6 +960,7 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
       } else if (phase == 1 && jacobi_fuses_zero(s)) {
         HIP_TRY(launch_jacobi_from_zero(L.n, L.diag.as<double>(), L.f.as<double>(), b,
                                         s->opt.omega, st));
+        s->acct(24.0 * L.n);  // diagonal, f, out
         std::swap(a, b);
         it = 1;
       } else if (phase == 2 && jacobi_fuses_prolong(s, l)) {
@@ -950,6 +969,7 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
                                            A.scol.p, A.sval.as<double>(), a,
                                            C.u.as<double>(), C.n, L.f.as<double>(), b,
                                            s->opt.omega, st));
+        s->acct(mat_bytes(A) + 24.0 * L.n + 8.0 * C.n);
         std::swap(a, b);
         it = 1;
       }
@@ -959,14 +979,18 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
           HIP_TRY(launch_dict_jacobi_prolong(A.n_rows, A.dict_ref(), a, L.f.as<double>(), b,
                                              s->opt.omega, F.n, F.u.as<double>(),
                                              prolong_out ? prolong_out : F.u.as<double>(), st));
+          s->acct(mat_bytes(A) + 24.0 * L.n + 16.0 * F.n);  // sweep + u_F in, u_F + P u out
         } else {
           HIP_TRY(launch_mat(CSR_JACOBI, A, a, L.f.as<double>(), b, s->opt.omega, st));
+          s->acct(mat_bytes(A) + 24.0 * L.n);  // matrix, f, x, out
         }
         std::swap(a, b);
       }
-      if (iters & 1)  // result sits in tmp: bring it home (keeps the graph static)
+      if (iters & 1) {  // result sits in tmp: bring it home (keeps the graph static)
         HIP_TRY(hipMemcpyAsync(L.u.p, L.tmp.p, sizeof(double) * L.n,
                                hipMemcpyDeviceToDevice, st));
+        s->acct(16.0 * L.n);
+      }
       return AMG_HIP_OK;
     }
     case AMG_HIP_SM_MULTICOLOR_GS:
@@ -982,6 +1006,9 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
 // one symmetric pass: colours 0..nc-1 then nc-1..0
 amg_hip_status enqueue_multicolor(amg_hip_solver* s, Level& L, hipStream_t st) {
   const DevMat& A = L.mc_mat;
+  // one symmetric pass = every row twice: matrix stream (dictionary: code words 8 B per word and
+  // row + 4 B dof id; SELL panels: indices + values + 4 B dof id), f, u written
+  s->acct(2.0 * ((L.mc_dict ? (8.0 * L.mc_words + 4.0) * L.n : mat_bytes(A) + 4.0 * L.n) + 16.0 * L.n));
   if (L.mc_dict && L.mc_start_dev.p && !s->opt.no_fusion) {  // small level: the whole pass in one launch
     HIP_TRY(launch_dict_gs_sweep(L.n_colors, L.mc_start_dev.as<int32_t>(), L.mc_start.back(), L.mc_words,
                                  L.mc_wmax, L.mc_codes.as<uint64_t>(), L.mc_rowid.as<int32_t>(),
@@ -1009,6 +1036,7 @@ amg_hip_status enqueue_residual(amg_hip_solver* s, int l) {
   Level& L = s->lv[l];
   HIP_TRY(launch_mat(CSR_RESID, L.A_rows, L.u.as<double>(), L.f.as<double>(), L.r.as<double>(),
                      1.0, s->stream));
+  s->acct(mat_bytes(L.A_rows) + 24.0 * L.n);  // matrix, f, u, r
   return AMG_HIP_OK;
 }
 
@@ -1017,7 +1045,15 @@ amg_hip_status enqueue_residual(amg_hip_solver* s, int l) {
 // over this rank's lines, the replicated rest below them (it begins by redoing the from-zero
 // sweep of its first level on the gathered right-hand side), the up-legs of the slab levels.
 enum { CYCLE_ALL = 0, CYCLE_SLAB_DOWN = 1, CYCLE_SLAB_TAIL = 2, CYCLE_SLAB_UP = 3 };
+amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part);
 amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
+  s->must_move[part] = 0;
+  s->acct_part = part;
+  const amg_hip_status r = enqueue_vcycle_body(s, part);
+  s->acct_part = -1;
+  return r;
+}
+amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
   const int nl = (int)s->lv.size();
   hipStream_t st = s->stream;
   const Slab& sb = s->slab;
@@ -1029,6 +1065,7 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
     Level& L = s->lv[k];
     HIP_TRY(launch_jacobi_from_zero(L.n, L.diag.as<double>(), L.f.as<double>(), L.tmp.as<double>(),
                                     s->opt.omega, st));
+    s->acct(24.0 * L.n);
     first_sweep_done = true;
   }
   const int down_from = part == CYCLE_SLAB_TAIL ? k : 0;
@@ -1047,6 +1084,8 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
       HIP_TRY(launch_patch_rb(false, true, L.n, A.patch_m, A.patch_ref(), L.tmp.as<double>(), L.f.as<double>(),
                               nullptr, C.n, L.u.as<double>(), s->opt.keep_residual ? L.r.as<double>() : nullptr,
                               C.f.as<double>(), C.u.as<double>(), 1, L.mc_checker, st));
+      // each launch: row types + x + f + out; the second also f_H, zeroed u_H (and r when kept)
+      s->acct(2.0 * 25.0 * L.n + 16.0 * C.n + (s->opt.keep_residual ? 8.0 * L.n : 0.0));
       first_sweep_done = false;
       continue;
     }
@@ -1062,6 +1101,14 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
                                 C.f.as<double>(), C.diag.as<double>(), C.tmp.as<double>(),
                                 s->opt.omega, st, ranged ? sb.down_lo[l] : 0,
                                 ranged ? sb.down_hi[l] : -1));
+      {  // row types + x + f + smoothed u; f_H, first coarse sweep, coarse diagonal
+        double frac = 1.0;
+        if (ranged && sb.down_hi[l] >= 0) {
+          const double lines = (double)((L.n + A.patch_m - 1) / A.patch_m);
+          frac = std::min(1.0, (double)(sb.down_hi[l] - sb.down_lo[l]) / lines);
+        }
+        s->acct(frac * (25.0 * L.n + 24.0 * C.n + (s->opt.keep_residual ? 8.0 * L.n : 0.0)));
+      }
       first_sweep_done = true;
       continue;
     }
@@ -1074,6 +1121,7 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
                                     s->opt.keep_residual ? L.r.as<double>() : nullptr, C.n,
                                     C.f.as<double>(), C.diag.as<double>(), C.tmp.as<double>(),
                                     s->opt.omega, st));
+      s->acct(mat_bytes(A) + 24.0 * L.n + 24.0 * C.n + (s->opt.keep_residual ? 8.0 * L.n : 0.0));
       continue;  // first_sweep_done stays true for level l+1
     }
     amg_hip_status r =
@@ -1091,6 +1139,9 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
                                          zero_known ? C.diag.as<double>() : nullptr,
                                          zero_known ? C.tmp.as<double>() : nullptr,
                                          C.u.as<double>(), s->opt.omega, st));
+      // matrix, u, f (r when kept); f_H and either the first coarse sweep + diagonal or the zeroed u_H
+      s->acct(mat_bytes(A) + 16.0 * L.n + (s->opt.keep_residual ? 8.0 * L.n : 0.0) +
+              (zero_known ? 24.0 : 16.0) * C.n);
       first_sweep_done = zero_known;
       continue;
     }
@@ -1103,12 +1154,14 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
       if (L.linear && s->opt.stencil_transfers) {                  // :278 + :281-282
         HIP_TRY(launch_linear_restrict(L.n, C.n, L.r.as<double>(), C.f.as<double>(),
                                        zero_known ? nullptr : C.u.as<double>(), st));
+        s->acct(8.0 * L.n + (zero_known ? 8.0 : 16.0) * C.n);
       } else {
         if (!zero_known) HIP_TRY(hipMemsetAsync(C.u.p, 0, sizeof(double) * C.n, st)); // :278
         const DevCsr& R = L.R_rows;
         HIP_TRY(launch_csr(CSR_SPMV, R.n_rows, R.nnz, R.max_block_nnz, R.max_row_nnz,
                            R.rowptr(), R.col(), R.v(), L.r.as<double>(), nullptr,
                            C.f.as<double>(), 1.0, 0, st));
+        s->acct(12.0 * R.nnz + 4.0 * C.n + 8.0 * L.n + (zero_known ? 8.0 : 16.0) * C.n);
       }
     }
   }
@@ -1117,6 +1170,8 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
       return fail(AMG_HIP_EINVAL, "a window solver (opt.window) runs by parts: amg_hip_window_run");
     Level& C = s->lv[nl - 1];
     HIP_TRY(launch_coarse(s->coarse, C.f.as<double>(), C.tmp.as<double>(), C.u.as<double>(), st));
+    // banded L D L^T solve: the band of L forwards and backwards, D, f, u
+    s->acct(16.0 * (double)C.n * (double)std::max<int64_t>(s->coarse.w, 1) + 24.0 * C.n);
   }
   // where the prolongation INTO level l lands: a level whose two post-sweeps run as one
   // launch reads u + P u_{l+1} from tmp (its second sweep then writes u; no in-place race
@@ -1136,6 +1191,7 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
                               L.mc_checker, st));
       HIP_TRY(launch_patch_rb(false, false, L.n, A.patch_m, A.patch_ref(), L.tmp.as<double>(), L.f.as<double>(),
                               nullptr, C.n, L.u.as<double>(), nullptr, nullptr, nullptr, 1, L.mc_checker, st));
+      s->acct(2.0 * 25.0 * L.n + 8.0 * C.n);
       continue;
     }
     if (patch_level_ok(s, l)) {  // :294-296 + :300 (both sweeps), one launch
@@ -1147,6 +1203,14 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
                               top ? L.tmp.as<double>() : L.u.as<double>(), L.f.as<double>(), uH, C.n,
                               top ? L.u.as<double>() : L.tmp.as<double>(), s->opt.omega, st,
                               ranged ? sb.up_lo[l] : 0, ranged ? sb.up_hi[l] : -1));
+      {
+        double frac = 1.0;
+        if (ranged && sb.up_hi[l] >= 0) {
+          const double lines = (double)((L.n + A.patch_m - 1) / A.patch_m);
+          frac = std::min(1.0, (double)(sb.up_hi[l] - sb.up_lo[l]) / lines);
+        }
+        s->acct(frac * (25.0 * L.n + 8.0 * C.n));  // row types + x + f + out; u_H
+      }
       continue;
     }
     // the last sweep of this level also prolongs into level l-1 when that fuses
@@ -1163,11 +1227,13 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
         HIP_TRY(launch_linear_prolong_to(L.n, C.n, C.u.as<double>(), L.u.as<double>(), up_target(l), st));
       else
         HIP_TRY(launch_linear_prolong_add(L.n, C.n, C.u.as<double>(), L.u.as<double>(), st));
+      s->acct(8.0 * C.n + 16.0 * L.n);
     } else {
       const DevCsr& P = L.P_rows;  // u_h = u_h + P u_H in one launch
       HIP_TRY(launch_csr(CSR_SPMV_ADD, P.n_rows, P.nnz, P.max_block_nnz, P.max_row_nnz,
                          P.rowptr(), P.col(), P.v(), C.u.as<double>(), L.u.as<double>(),
                          L.u.as<double>(), 1.0, 0, st));
+      s->acct(12.0 * P.nnz + 4.0 * L.n + 8.0 * C.n + 16.0 * L.n);
     }
     if (pair_up_ok(s, l)) {                                        // :300, both sweeps
       Level& F = s->lv[l - 1];
@@ -1175,6 +1241,7 @@ amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
       HIP_TRY(launch_dict_pair_up(A.n_rows, A.dict_ref(), A.dict_hb, L.tmp.as<double>(),
                                   L.f.as<double>(), L.u.as<double>(), s->opt.omega, F.n,
                                   F.u.as<double>(), up_target(l - 1), st));
+      s->acct(mat_bytes(A) + 24.0 * L.n + 16.0 * F.n);
       continue;
     }
     amg_hip_status r = enqueue_smooth(s, l, 0, into, into >= 0 ? up_target(into) : nullptr);  // :300
@@ -2554,7 +2621,8 @@ amg_hip_status amg_hip_set_vec(amg_hip_solver* s, int32_t level, int32_t which,
 int64_t amg_hip_coarse_halfbw(const amg_hip_solver* s) { return s ? s->coarse.w : -1; }
 int32_t amg_hip_coarse_solve_kind(const amg_hip_solver* s) { return s ? s->coarse.kind : -1; }
 
-static void layout_of(const DevMat& A, int32_t* layout, int64_t* matrix_stream_bytes) {
+namespace {
+void layout_of(const DevMat& A, int32_t* layout, int64_t* matrix_stream_bytes) {
   int32_t lay;
   int64_t bytes;
   if (A.dict) {
@@ -2571,6 +2639,7 @@ static void layout_of(const DevMat& A, int32_t* layout, int64_t* matrix_stream_b
   if (layout) *layout = lay;
   if (matrix_stream_bytes) *matrix_stream_bytes = bytes;
 }
+}  // namespace
 amg_hip_status amg_hip_level_layout(const amg_hip_solver* s, int32_t level, int32_t* layout,
                                     int64_t* matrix_stream_bytes) {
   if (!s || level < 0 || level >= (int32_t)s->lv.size())
@@ -2602,23 +2671,43 @@ amg_hip_status amg_hip_cycle_bytes(const amg_hip_solver* s, double* cycle_bytes,
 amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
                                           double* avg_ms, double* min_ms) {
   if (!s || n_launches < 1) return fail(AMG_HIP_EINVAL, "bad argument");
-  if (s->opt.smoother != AMG_HIP_SM_JACOBI)
-    return fail(AMG_HIP_EUNSUPPORTED, "profile_fine_sweep: only for the Jacobi smoother");
+  if (s->opt.smoother != AMG_HIP_SM_JACOBI && s->opt.smoother != AMG_HIP_SM_MULTICOLOR_GS)
+    return fail(AMG_HIP_EUNSUPPORTED, "profile_fine_sweep: only for the Jacobi and multicolour smoothers");
   amg_hip_status r = set_device(s);
   if (r != AMG_HIP_OK) return r;
   Level& L = s->lv[0];
   const DevMat& A = L.A_cols();
+  const bool mc = s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS;
+  const bool mc_patch = mc && mc_patch_ok(s, 0);
+  // multicolour, colour kernels: the launch updates u in place; keep a copy in r
+  if (mc && !mc_patch)
+    HIP_TRY(hipMemcpyAsync(L.r.p, L.u.p, sizeof(double) * L.n, hipMemcpyDeviceToDevice, s->stream));
   std::vector<hipEvent_t> ev(2 * (size_t)n_launches);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   // keep u: sweep u -> tmp only (u itself is never written).  With K-Patch the launch is the
   // level's whole down-leg (2 sweeps + residual + restriction + first coarse sweep); it also
   // rewrites f and tmp of level 1, which every V-cycle recomputes before use.
-  const bool patch = patch_level_ok(s, 0);
+  const bool patch = !mc && patch_level_ok(s, 0);
   // slab-sharded solver: this rank's launch, i.e. its own lines + halo only
   const bool slab = patch && s->slab.levels > 0 && s->slab.world > 1;
   for (int i = 0; i < n_launches; ++i) {
     HIP_TRY(hipEventRecord(ev[2 * i], s->stream));
-    if (patch) {
+    if (mc_patch) {  // colours 0, 1 of the pass as patch stages: u -> tmp
+      HIP_TRY(launch_patch_rb(false, false, L.n, L.A_rows.patch_m, L.A_rows.patch_ref(), L.u.as<double>(),
+                              L.f.as<double>(), nullptr, s->lv[1].n, L.tmp.as<double>(), nullptr, nullptr,
+                              nullptr, 0, L.mc_checker, s->stream));
+    } else if (mc) {  // colour 0 of the forward half
+      if (L.mc_dict)
+        HIP_TRY(launch_dict_gs_color(L.mc_start[0], L.mc_start[1] - L.mc_start[0], L.mc_words, L.mc_wmax,
+                                     L.mc_codes.as<uint64_t>(), L.mc_rowid.as<int32_t>(),
+                                     L.mc_doff.as<int32_t>(), L.mc_dval.as<double>(), L.mc_ntab,
+                                     L.f.as<double>(), L.u.as<double>(), s->stream));
+      else
+        HIP_TRY(launch_sell_gs_color(L.mc_mat.n_rows, L.mc_mat.max_width, L.mc_mat.soff.as<int64_t>(),
+                                     L.mc_mat.scol.as<int32_t>(), L.mc_mat.sval.as<double>(),
+                                     L.mc_rowid.as<int32_t>(), L.mc_start[0], L.mc_start[1] - L.mc_start[0],
+                                     L.f.as<double>(), L.u.as<double>(), s->stream));
+    } else if (patch) {
       Level& C = s->lv[1];
       HIP_TRY(launch_patch_down(true, L.n, A.patch_m, A.patch_ref(), L.u.as<double>(),
                                 L.f.as<double>(), L.tmp.as<double>(), nullptr, C.n, C.f.as<double>(),
@@ -2630,6 +2719,8 @@ amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
     }
     HIP_TRY(hipEventRecord(ev[2 * i + 1], s->stream));
   }
+  if (mc && !mc_patch)
+    HIP_TRY(hipMemcpyAsync(L.u.p, L.r.p, sizeof(double) * L.n, hipMemcpyDeviceToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   double sum = 0, mn = 1e30;
   for (int i = 0; i < n_launches; ++i) {
@@ -2641,6 +2732,23 @@ amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
   for (auto& e : ev) (void)hipEventDestroy(e);
   if (avg_ms) *avg_ms = sum / n_launches;
   if (min_ms) *min_ms = mn;
+  return AMG_HIP_OK;
+}
+
+amg_hip_status amg_hip_cycle_must_move(amg_hip_solver* s, int32_t part, double* bytes) {
+  if (!s || !bytes || part < 0 || part > 3) return fail(AMG_HIP_EINVAL, "bad argument");
+  if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "host_only solver has no device cycle");
+  if (part == CYCLE_ALL && s->must_move[0] == 0.0 && !s->opt.window) {
+    // not enqueued yet: capturing the graph walks the cycle without running it
+    amg_hip_status r = set_device(s);
+    if (r != AMG_HIP_OK) return r;
+    if (s->opt.use_graph) {
+      if ((r = ensure_graph(s)) != AMG_HIP_OK) return r;
+    } else {
+      return fail(AMG_HIP_EINVAL, "amg_hip_cycle_must_move: run a V-cycle first");
+    }
+  }
+  *bytes = s->must_move[part];
   return AMG_HIP_OK;
 }
 
@@ -2665,7 +2773,10 @@ amg_hip_status amg_hip_fine_sweep_info(const amg_hip_solver* s, char* name, int3
       bytes = 25.0 * (double)L.n;
     } else {
       std::snprintf(name, (size_t)name_cap, "%s", L.mc_dict ? "dict_gs_color_kernel" : "sell_kernel<5>");
-      bytes = 0.5 * (12.0 * (double)L.nnz_struct + 28.0 * (double)L.n);
+      const double rows = (double)(L.mc_start.size() > 1 ? L.mc_start[1] - L.mc_start[0] : L.n);
+      // rows of colour 0: code words + dof id (dictionary) or their share of the panels, f, u written
+      bytes = L.mc_dict ? rows * (8.0 * L.mc_words + 4.0 + 16.0)
+                        : rows / (double)L.n * (12.0 * (double)L.nnz_struct + 28.0 * (double)L.n);
     }
   } else if (A.dict && patch_level_ok(s, 0)) {
     // row types + x + f + smoothed u per fine row; f_H, first coarse sweep, coarse diagonal

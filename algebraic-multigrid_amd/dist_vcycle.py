@@ -880,18 +880,24 @@ def _result_line(args, world, L, dv, results, best, notes, rehearsal, avg_ms, sw
                 "layout": lay, "csr_formula_bytes_per_sweep": sweep_bytes,
                 "note": "per rank: rank 0's row block; PMC traffic is collected on the N=1 line"}
     n_dist = notes.get(best + "_distributed_levels", dv.n_dist)   # of the reported transport
+    dim = getattr(args, "dim", 2)
+    multicolor = getattr(args, "smoother", "jacobi") == "multicolor"
+    problem = (f"2D 5-point Poisson {args.n}x{args.n} (Grid::laplacian/rhs)" if dim == 2 else
+               f"3D 7-point Poisson {args.n}^3 (the 7-point analogue of Grid::laplacian/rhs)")
+    smoother = ("multicolour symmetric GS 1+1 passes" if multicolor else
+                f"true Jacobi omega={args.omega} {args.sweeps}+{args.sweeps} sweeps")
     return {
-        "metric": metric_string(args.n),
+        "metric": metric_string(args.n, dim),
         "value": args.steps / dt, "unit": "V-cycles/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": (f"2D 5-point Poisson {args.n}x{args.n} (Grid::laplacian/rhs), true Jacobi "
-                         f"omega={args.omega} {args.sweeps}+{args.sweeps} sweeps, {L}-level V-cycle, "
+            "workload": (f"{problem}, {smoother}, {L}-level V-cycle, "
                          f"row-block shards over {world} GPUs ({n_dist} distributed levels, "
                          f"rest agglomerated), fp64"),
-            "n": args.n, "levels": L, "distributed_levels": n_dist, "rehearsal": rehearsal,
+            "n": args.n, "dim": dim, "smoother": "multicolor" if multicolor else "jacobi",
+            "levels": L, "distributed_levels": n_dist, "rehearsal": rehearsal,
             "dist_min_rows": args.dist_min_rows, "setup_seconds": time.time() - t0,
             "halo_exchange": best, "exchange_modes": notes,
             "vcycles_per_sec_by_exchange": {k: args.steps / v[0] for k, v in results.items()},
@@ -921,13 +927,23 @@ def bench(args):
                                 device_id=torch.device("cuda", local))
     be = HipBackend(local)
     from bench import n_levels_for, HBM_PEAK_GBS
+    import window_vcycle
     t0 = time.time()
-    colptr, rowind, val = amg.laplacian(args.n)
-    b = amg.rhs(args.n)
-    L = args.levels or n_levels_for(args.n)
-    hier = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_JACOBI,
-                         smoother_iters=args.sweeps, omega=args.omega, host_only=True)
-    del colptr, rowind, val
+    dim = getattr(args, "dim", 2)
+    multicolor = getattr(args, "smoother", "jacobi") == "multicolor"
+    # BASELINE configs 4 / 5 (multicolour GS, 3-D): replicated and window-sharded only -- the
+    # per-sweep and slab designs are true-Jacobi 2-D and start from a host copy of the hierarchy
+    general = dim == 3 or multicolor
+    w_smoother = window_vcycle.SM_MULTICOLOR if multicolor else window_vcycle.SM_JACOBI
+    w_iters = 1 if multicolor else args.sweeps
+    L = args.levels or n_levels_for(args.n, dim=dim)
+    hier = None
+    if not general:
+        colptr, rowind, val = amg.laplacian(args.n)
+        b = amg.rhs(args.n)
+        hier = amg.Multigrid(colptr, rowind, val, b, L, smoother=amg.SM_JACOBI,
+                             smoother_iters=args.sweeps, omega=args.omega, host_only=True)
+        del colptr, rowind, val
     def timed(dv):
         for _ in range(args.warmup):
             dv.vcycle()
@@ -975,8 +991,12 @@ def bench(args):
     # (1) Replicated: nothing is distributed, every rank runs the whole (fused, K-Patch) single-GPU
     # cycle.  No data-path exchange at all, so it cannot hang; it is the single-GPU result every
     # sharded candidate has to reproduce bit for bit, and the line that is printed if one hangs.
-    dvr = DistributedVcycle(hier, b, be, rank, world, omega=args.omega, sweeps=args.sweeps,
-                            dist_min_rows=1 << 62, host_staged=rehearsal, comm="p2p")
+    if general:
+        dvr = window_vcycle.ReplicatedVcycle(amg, be.device, be._stream, dim, args.n, L, w_smoother, w_iters,
+                                             args.omega)
+    else:
+        dvr = DistributedVcycle(hier, b, be, rank, world, omega=args.omega, sweeps=args.sweeps,
+                                dist_min_rows=1 << 62, host_staged=rehearsal, comm="p2p")
     results["replicated"] = timed(dvr)
     notes["replicated"] = "ok"
     notes["replicated_distributed_levels"] = dvr.n_dist
@@ -985,7 +1005,7 @@ def bench(args):
     # (2) Per-sweep halo exchange through torch.distributed isend/irecv + all_gather (RCCL): one
     # exchange before every sweep, residual and transfer of the distributed levels.
     dv = dvr
-    if world > 1:
+    if world > 1 and not general:
         stash_line("p2p exchange hung")
         dog.arm("p2p")
         try:
@@ -1012,7 +1032,7 @@ def bench(args):
     # halo, two exchanges per cycle (grouped send/recv of the level-0 halo lines, one all-gather),
     # the rest replicated.  Same RCCL primitives as "p2p"; kept only if it reproduces its result.
     dvs = None
-    if world > 1 and args.comm in ("safe", "auto", "slab") and args.sweeps == 2:
+    if world > 1 and args.comm in ("safe", "auto", "slab") and args.sweeps == 2 and not general:
         import slab_vcycle
         stash_line("slab exchange hung")
         dog.arm("slab")
@@ -1041,7 +1061,48 @@ def bench(args):
         finally:
             dog.disarm()
 
-    if dv.n_dist and "p2p" in results and args.comm not in ("p2p", "safe", "slab"):
+    # Window sharding (window_vcycle.py): every rank sets up and stores only its window of the
+    # distributed levels; general kernels, so multicolour GS and 3-D shard too.  Two exchanges per
+    # cycle with the same RCCL primitives; kept only if it reproduces the replicated result.
+    dvw = None
+    if world > 1 and args.comm in ("safe", "auto", "window"):
+        stash_line("window exchange hung")
+        dog.arm("window")
+        try:
+            if os.environ.get("AMG_DIST_FORCE_HANG") == "window":
+                time.sleep(args.comm_timeout + 30)
+            k = args.window_levels
+            if k < 0:
+                k = window_vcycle.auto_levels(dim, args.n, world, L, w_smoother, w_iters, args.window_min_rows)
+            if k < 1:
+                raise ValueError("no level is large enough to distribute (or the halo does not fit a block)")
+            plan = window_vcycle.WindowPlan(dim, args.n, rank, world, k, w_smoother, w_iters)
+            eng = window_vcycle.HipWindowEngine(amg, be.device, be._stream, plan, args.omega,
+                                                patch_min_rows=args.slab_patch_min_rows)
+            comm = window_vcycle.TorchComm(rank, world, host_staged=rehearsal, sync=be.sync,
+                                           device=None if rehearsal else be.device)
+            dvw = window_vcycle.WindowVcycle(eng, plan, comm, L)
+            notes["window_distributed_levels"] = k
+            notes["window_halo_units"] = plan.halo
+            notes["window_rows_level0_per_rank"] = plan.window_rows(0)
+            res = timed(dvw)
+            if same_result(res, ref):
+                results["window"] = res
+                notes["window"] = "ok"
+                notes["window_must_move_bytes_per_rank"] = (eng.mg.cycle_must_move(1) + eng.mg.cycle_must_move(3)
+                                                            + eng.tail.cycle_must_move(0))
+            else:
+                notes["window"] = "ran but did not reproduce the single-GPU result; discarded"
+        except (amg.AmgHipError, ValueError, window_vcycle.WindowUnsupported) as ex:
+            notes["window"] = f"unavailable: {ex}"
+        except Exception as ex:   # noqa: BLE001 -- a candidate that fails must not cost the line we already have
+            notes["window"] = f"failed: {type(ex).__name__}: {ex}"
+        try:
+            agree("window")
+        finally:
+            dog.disarm()
+
+    if dv.n_dist and "p2p" in results and args.comm not in ("p2p", "safe", "slab", "window"):
         stash_line("alternative exchange hung")
         # cheaper exchanges pay off on smaller levels (results do not depend on the
         # threshold); the in-graph exchange is timed with two thresholds because the
@@ -1075,7 +1136,8 @@ def bench(args):
                 notes[mode] = f"unavailable: {ex}"
             finally:
                 dog.disarm()
-    hier.close()
+    if hier is not None:
+        hier.close()
     best = min(results, key=lambda k: results[k][0])
     dt, rss0, rss = results[best][:3]
     # dominant kernel: this rank's level-0 Jacobi sweep (HIP events on the rank's stream)
@@ -1098,14 +1160,18 @@ def bench(args):
     best_nd = notes.get(best + "_distributed_levels")
     whole = dvr if best_nd == 0 else None
     roof_whole = None
-    if best == "slab" or (whole is not None and hasattr(whole.tail, "mg")):
+    if general and best == "replicated":
+        whole = dvr
+    if best in ("slab", "window") or (whole is not None and (general or hasattr(whole.tail, "mg"))):
         from bench import fine_sweep_roofline
-        mgw = dvs.eng.mg if best == "slab" else whole.tail.mg
+        mgw = dvs.eng.mg if best == "slab" else (dvw.eng.mg if best == "window" else
+                                                 (whole.mg if general else whole.tail.mg))
         lay_id, mat_b = mgw.level_layout(0)
         lay_nm = {amg.LAYOUT_CSR: "csr", amg.LAYOUT_SELL: "sell", amg.LAYOUT_DICT: "dict"}[lay_id]
         roof_whole = fine_sweep_roofline(amg, mgw, args, lay_nm, mat_b, mgw.get_n_dofs(0), mgw.cycle_bytes()[1],
                                          launches=max(8, args.profile_launches // 2))
         roof_whole["note"] = ("per rank: rank 0's lines + halo of the level-0 down-leg (slab sharding)" if best == "slab"
+                              else "per rank: the level-0 launch over rank 0's window (owned units + halo)" if best == "window"
                               else "per rank: every rank runs the whole cycle (nothing is distributed)")
     out = None
     if rank == 0:
@@ -1124,6 +1190,8 @@ def bench(args):
     dvr.close()
     if dvs is not None:
         dvs.close()
+    if dvw is not None:
+        dvw.close()
     dist.barrier()
     dist.destroy_process_group()
     return out

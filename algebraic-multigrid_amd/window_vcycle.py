@@ -150,14 +150,22 @@ class WindowPlan:
 # ------------------------------------------------------------------ comm ---------
 class TorchComm:
     """torch.distributed: "nccl" (= RCCL over xGMI) with device tensors, "gloo" with CPU tensors,
-    or gloo next to device tensors (host_staged: every exchange goes through host copies)."""
+    or gloo next to device tensors (host_staged: every exchange goes through host copies).
+    device: where a CPU tensor (setup-time flags, colours) is staged for a backend that only moves
+    device memory (nccl)."""
 
-    def __init__(self, rank, world, group=None, host_staged=False, sync=None):
+    def __init__(self, rank, world, group=None, host_staged=False, sync=None, device=None):
         self.rank, self.world, self.group = rank, world, group
-        self.host_staged, self._sync = bool(host_staged), sync
+        self.host_staged, self._sync, self.device = bool(host_staged), sync, device
 
-    def _stage(self, t):
-        return t.cpu() if self.host_staged else t
+    def _wire(self, t):
+        """the tensor the backend can move for t: a host copy (host_staged), a device copy of a CPU
+        tensor (nccl), or t itself"""
+        if self.host_staged:
+            return t if t.device.type == "cpu" else t.cpu()
+        if self.device is not None and t.device.type == "cpu":
+            return t.to(self.device)
+        return t
 
     def neighbor_exchange(self, send_prev, recv_prev, send_next, recv_next):
         """grouped send/recv with rank-1 / rank+1; tensors or None; received in place"""
@@ -168,13 +176,14 @@ class TorchComm:
         def post(kind, t, peer):
             if t is None or t.numel() == 0:
                 return
-            if kind is dist.irecv and self.host_staged:
-                h = torch.empty(t.shape, dtype=t.dtype)
-                back.append((t, h))
-                t = h
-            elif self.host_staged:
-                t = t.cpu()
-            ops.append(dist.P2POp(kind, t, peer, self.group))
+            if kind is dist.irecv:
+                wt = self._wire(t)
+                if wt is not t:
+                    wt = torch.empty(t.shape, dtype=t.dtype, device=wt.device)
+                    back.append((t, wt))
+            else:
+                wt = self._wire(t)
+            ops.append(dist.P2POp(kind, wt, peer, self.group))
 
         if r > 0:
             post(dist.irecv, recv_prev, r - 1)
@@ -185,41 +194,39 @@ class TorchComm:
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        for dst, h in back:
-            dst.copy_(h)
+        for dst, wt in back:
+            dst.copy_(wt)
 
     def all_gather_blocks(self, inp, out):
         """out = [inp of rank 0 | inp of rank 1 | ...] (equal blocks)"""
         if self.world == 1:
             out.copy_(inp)
             return
-        if self.host_staged:
-            if self._sync:
-                self._sync()
-            ho = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_gather_into_tensor(ho, inp.cpu(), group=self.group)
-            out.copy_(ho)
-        else:
+        if self.host_staged and self._sync:
+            self._sync()
+        wi = self._wire(inp)
+        if wi is inp:
             dist.all_gather_into_tensor(out, inp, group=self.group)
+        else:
+            wo = torch.empty(out.shape, dtype=out.dtype, device=wi.device)
+            dist.all_gather_into_tensor(wo, wi, group=self.group)
+            out.copy_(wo)
 
     def all_reduce_sum(self, t):
         if self.world == 1:
             return t
-        if self.host_staged:
-            if self._sync:
-                self._sync()
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
-            return h
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t
+        if self.host_staged and self._sync:
+            self._sync()
+        wt = self._wire(t)
+        dist.all_reduce(wt, op=dist.ReduceOp.SUM, group=self.group)
+        return wt
 
     def all_gather_numpy(self, arr, device=None):
         """setup-time gather of one numpy array per rank (different lengths)"""
         arr = np.ascontiguousarray(arr)
         if self.world == 1:
             return [arr]
-        dev = "cpu" if (self.host_staged or device is None) else device
+        dev = "cpu" if (self.host_staged or self.device is None) else self.device
         cnt = torch.tensor([arr.size], dtype=torch.int64, device=dev)
         cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
         dist.all_gather(cnts, cnt, group=self.group)
@@ -269,10 +276,9 @@ class WindowVcycle:
         cnt = np.diff(colptr[a:b + 1]).astype(np.int32)
         shift = p.w0 * self.pk                              # window row -> global row
         rows = (rowind[q0:q1].astype(np.int64) + shift).astype(np.int32)
-        dev = self.eng.u0.device if self.eng.u0.device.type != "cpu" else None
-        cnts = self.comm.all_gather_numpy(cnt, dev)
-        rws = self.comm.all_gather_numpy(rows, dev)
-        vls = self.comm.all_gather_numpy(val[q0:q1], dev)
+        cnts = self.comm.all_gather_numpy(cnt)
+        rws = self.comm.all_gather_numpy(rows)
+        vls = self.comm.all_gather_numpy(val[q0:q1])
         cnt_all = np.concatenate(cnts)
         if cnt_all.size != self.nk:
             raise WindowUnsupported(f"gathered level {k} has {cnt_all.size} columns, expected {self.nk}")
@@ -470,3 +476,52 @@ class HipWindowEngine:
         if self.mg is not None:
             self.mg.close()
             self.mg = None
+
+
+# ------------------------------------------------------- bench.py --gpus N -------
+class ReplicatedVcycle:
+    """Nothing distributed: every rank runs the whole single-GPU cycle (amg_hip_create_poisson).
+    No exchange on the data path; it is the result every sharded candidate has to reproduce."""
+
+    n_dist = 0
+
+    def __init__(self, amg, device, stream, dim, n, L, smoother, iters, omega, use_graph=True):
+        sm = amg.SM_JACOBI if smoother == SM_JACOBI else amg.SM_MULTICOLOR_GS
+        self.device, self._stream = device, stream
+        self.mg = amg.Multigrid.poisson(n, L, dim=dim, smoother=sm, smoother_iters=iters, omega=omega,
+                                        device=device.index, stream=stream.cuda_stream, use_graph=use_graph)
+        ptr, m = self.mg.vec_dev_ptr(0, "u")
+        self._u0 = torch.as_tensor(_DevArray(ptr, m), device=device)
+
+    def vcycle(self):
+        self.mg.vcycle(1)
+
+    def rss(self):
+        return self.mg.rss()
+
+    def solution_checksum(self):
+        self._stream.synchronize()
+        return int(self._u0.view(torch.int64).sum().item())
+
+    def timed_out(self):
+        return False
+
+    def close(self):
+        self._u0 = None
+        self.mg.close()
+
+
+def auto_levels(dim, n, world, L, smoother, iters, min_rows, max_overhead=0.35):
+    """Distributed levels for bench.py: every level of at least `min_rows` rows, as long as the
+    windows stay feasible and the redundantly recomputed halo stays below `max_overhead` of the
+    owned block."""
+    best = 0
+    for k in range(1, L):
+        try:
+            p = WindowPlan(dim, n, 0, world, k, smoother, iters)
+        except ValueError:
+            break
+        if p.global_rows(k - 1) < min_rows or 2.0 * p.halo / p.chunk > max_overhead:
+            break
+        best = k
+    return best

@@ -29,7 +29,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CPU_FLAGS = ("-O2 -ffp-contract=off", "-O3 -march=native -ffp-contract=off")
 
 
-def metric_string(n):
+def metric_string(n, dim=2):
+    if dim == 3:
+        return f"V-cycles/sec, 3D 7-point Poisson N={n}^3 (fine-grid smoother HBM GB/s under roofline)"
     return f"V-cycles/sec, 2D Poisson N={n}^2 (fine-grid smoother HBM GB/s under roofline)"
 
 
@@ -63,10 +65,10 @@ def pmc_traffic(kernel_prefix, n):
     return None, f"no PMC record for this build (source_sha16 {sha}); see tools/pmc_traffic.py"
 
 
-def n_levels_for(n, coarsest_max=511):
+def n_levels_for(n, coarsest_max=511, dim=2):
     """Smallest level count whose coarsest level has <= coarsest_max dofs
     (n_H = (n_h+1)/2 - 1, multigrid.hpp:127-130)."""
-    dofs, levels = n * n, 1
+    dofs, levels = n ** dim, 1
     while dofs > coarsest_max:
         dofs = (dofs + 1) // 2 - 1
         levels += 1
@@ -79,21 +81,33 @@ def cpu_baseline(args):
     1 warm-up, median), once per flag set of CPU_FLAGS.  `value` is the faster of the two."""
     from oracle import oracle as O
     n = args.cpu_n or args.n
-    L = args.levels or n_levels_for(n)
-    A, b = O.laplacian(n), O.rhs(n)
+    dim = args.dim
+    L = args.levels or n_levels_for(n, dim=dim)
+    A, b = O.laplacian(n, dim), O.rhs(n, dim)
+    colors = None
+    if args.smoother == "multicolor":   # the twin replays the product's greedy colouring (host code)
+        import amg_ctypes as amg
+        h = amg.Multigrid(A.colptr, A.rowind, A.val, b, L, smoother=amg.SM_MULTICOLOR_GS, host_only=True)
+        colors = [h.get_colors(l) for l in range(L)]
+        h.close()
     runs = {}
     for flags in CPU_FLAGS:
         lib = O.lib() if flags == CPU_FLAGS[0] else O.lib_variant(flags)
         t0 = time.time()
-        mg = O.Multigrid(A, b, L, smoother=O.SM_TRUE_JACOBI, smoother_iters=args.sweeps,
-                         omega=args.omega, library=lib)
+        if colors is None:
+            mg = O.Multigrid(A, b, L, smoother=O.SM_TRUE_JACOBI, smoother_iters=args.sweeps,
+                             omega=args.omega, library=lib)
+        else:
+            mg = O.Multigrid(A, b, L, smoother=O.SM_MULTICOLOR, smoother_iters=1, library=lib)
+            for l, (c, nc) in enumerate(colors):
+                mg.set_colors(l, c, nc)
         setup = time.time() - t0
         mg.time_vcycles(1)  # warm-up
         times = sorted(mg.time_vcycles(1) for _ in range(args.cpu_cycles))
         del mg
         runs[flags] = {"vcycles_per_sec": 1.0 / times[len(times) // 2], "setup_seconds": setup}
     best = max(runs, key=lambda k: runs[k]["vcycles_per_sec"])
-    scale = (n * n) / float(args.n * args.n)   # 1 unless --cpu-n asks for a smaller sample
+    scale = (n ** dim) / float(args.n ** dim)   # 1 unless --cpu-n asks for a smaller sample
     return {
         "value": runs[best]["vcycles_per_sec"] * scale,
         "unit": "V-cycles/s",
@@ -103,9 +117,9 @@ def cpu_baseline(args):
         "flags": best,
         "by_flags": runs,
         "sample": (f"{args.cpu_cycles} vcycle() calls (median, after 1 warm-up) of the CPU oracle "
-                   f"(g++ {best}) on the {n}x{n} instance ({L} levels, same smoother, same "
+                   f"(g++ {best}) on the {n}^{dim} instance ({L} levels, same smoother, same "
                    f"omega)" + ("" if n == args.n else
-                                f", rate scaled by {n * n}/{args.n * args.n} dofs to {args.n}x{args.n}")),
+                                f", rate scaled by {n ** dim}/{args.n ** dim} dofs to {args.n}^{dim}")),
     }
 
 
@@ -125,17 +139,18 @@ def run_single(args):
     # setup on the device end to end (generator, Galerkin chain, encoder: amg_hip_create_poisson);
     # --host-setup hands Grid-generated host arrays to the general constructor instead
     t0 = time.time()
-    L = args.levels or n_levels_for(args.n)
+    dim = args.dim
+    L = args.levels or n_levels_for(args.n, dim=dim)
     kw = (dict(smoother=amg.SM_MULTICOLOR_GS, smoother_iters=1) if args.smoother == "multicolor" else
           dict(smoother=amg.SM_JACOBI, smoother_iters=args.sweeps, omega=args.omega,
                fast_coarse_solve=args.fast_coarse))
     if args.host_setup:
-        colptr, rowind, val = amg.laplacian(args.n)
-        b = amg.rhs(args.n)
+        colptr, rowind, val = amg.laplacian(args.n, dim)
+        b = amg.rhs(args.n, dim)
         mg = amg.Multigrid(colptr, rowind, val, b, L, use_graph=not args.no_graph, **kw)
         del colptr, rowind, val
     else:
-        mg = amg.Multigrid.poisson(args.n, L, use_graph=not args.no_graph, **kw)
+        mg = amg.Multigrid.poisson(args.n, L, dim=dim, use_graph=not args.no_graph, **kw)
     mg.sync()
     setup_s = time.time() - t0
     mg.vcycle(args.warmup)
@@ -153,8 +168,11 @@ def run_single(args):
     sizes = [mg.get_n_dofs(l) for l in range(L)]
     lay, mat_bytes = mg.level_layout(0)
     lay_name = {amg.LAYOUT_CSR: "csr", amg.LAYOUT_SELL: "sell", amg.LAYOUT_DICT: "dict"}[lay]
+    must = mg.cycle_must_move()
+    problem = (f"2D 5-point Poisson {args.n}x{args.n} (Grid::laplacian/rhs)" if dim == 2 else
+               f"3D 7-point Poisson {args.n}^3 (the 7-point analogue of Grid::laplacian/rhs)")
     out = {
-        "metric": metric_string(args.n),
+        "metric": metric_string(args.n, dim),
         "value": args.steps / dt,
         "unit": "V-cycles/s",
         "n_gpus": 1,
@@ -167,26 +185,29 @@ def run_single(args):
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": (f"2D 5-point Poisson {args.n}x{args.n} (Grid::laplacian/rhs), "
+            "workload": (problem + ", "
                          + (f"true Jacobi smoother omega={args.omega} {args.sweeps}+{args.sweeps} sweeps"
                             if args.smoother == "jacobi" else "multicolour symmetric GS 1+1 passes")
                          + f", {L}-level V-cycle, coarsest {sizes[-1]} dofs, fp64, 1xMI355X; "
                            "smoother has no counterpart in the reference: pinned to the oracle twin"),
-            "n": args.n, "levels": L, "smoother": args.smoother, "omega": args.omega,
+            "n": args.n, "dim": dim, "levels": L, "smoother": args.smoother, "omega": args.omega,
             "sweeps": args.sweeps, "graph": not args.no_graph, "coarse_solve": mg.coarse_solve_kind(),
             "layout": lay_name, "setup_seconds": setup_s,
             "rss_after_warmup": rss0, "rss_after_steps": rss,
             "rss_ratio_per_cycle": (rss / rss0) ** (1.0 / args.steps) if rss0 > 0 else None,
             "csr_formula_cycle_bytes": cyc_bytes,
+            # the whole cycle against the HBM roof: bytes every launch of the cycle has to move in the
+            # layout it streams (amg_hip_cycle_must_move) / measured time per cycle
+            "whole_cycle": {"must_move_bytes": must, "GBps": must / (dt / args.steps) / 1e9,
+                            "frac_of_hbm_peak": must / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
         },
-        "roofline": fine_sweep_roofline(amg, mg, args, lay_name, mat_bytes, sizes[0], sweep_bytes)
-        if args.smoother == "jacobi" else None,
+        "roofline": fine_sweep_roofline(amg, mg, args, lay_name, mat_bytes, sizes[0], sweep_bytes),
     }
     mg.close()
     # the same workload with the level matrices as plain CSR panels (SELL-64): the layout
     # SURVEY 8(d)'s CSR-formula bytes describe; a second, shorter measurement in the same run
     if lay_name == "dict" and args.smoother == "jacobi" and not args.no_csr_ref:
-        ref = amg.Multigrid.poisson(args.n, L, smoother=amg.SM_JACOBI, smoother_iters=args.sweeps,
+        ref = amg.Multigrid.poisson(args.n, L, dim=dim, smoother=amg.SM_JACOBI, smoother_iters=args.sweeps,
                                     omega=args.omega, use_graph=not args.no_graph, layout=amg.LAYOUT_SELL)
         ref.vcycle(args.warmup)
         ref.sync()
@@ -199,11 +220,14 @@ def run_single(args):
         roof2 = fine_sweep_roofline(amg, ref, args, "sell", mat2, sizes[0], sweep_bytes,
                                     launches=max(8, args.profile_launches // 2))
         rss_ref = ref.rss()
+        must2 = ref.cycle_must_move()
         ref.close()
         out["config"]["csr_layout_reference"] = {
             "layout": "sell (CSR sliced into 64-row panels, 16-bit relative columns)",
             "vcycles_per_sec": k / dt2, "ms_per_step": dt2 / k * 1e3, "steps": k,
             "rss_after_warmup_plus_steps": rss_ref, "roofline": roof2,
+            "whole_cycle": {"must_move_bytes": must2, "GBps": must2 / (dt2 / k) / 1e9,
+                            "frac_of_hbm_peak": must2 / (dt2 / k) / 1e9 / HBM_PEAK_GBS},
         }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args)
@@ -223,7 +247,12 @@ def fine_sweep_roofline(amg, mg, args, lay_name, mat_bytes, n0, csr_formula_byte
       saves are traffic it no longer causes; they show up in V-cycles/s, not in this
       fraction.  The library reports the figure (amg_hip_fine_sweep_info)."""
     avg_ms, min_ms, sweeps_per_launch, kname, must_move = mg.profile_fine_sweep(launches or args.profile_launches)
-    if kname.startswith("patch_down"):
+    if kname.startswith("patch_rb"):
+        model = ("K-Patch form of the multicolour pass on the red-black level 0: one launch = two colour "
+                 "stages over the level: n*(1 B row type + x + f + out)")
+    elif kname.startswith("dict_gs_color") or kname.startswith("sell_kernel<5"):
+        model = "rows of colour 0: matrix stream of those rows (code words / panels + dof id) + f + u written"
+    elif kname.startswith("patch_down"):
         model = ("K-Patch down-leg of level 0 in one launch (2 Jacobi sweeps + residual + restriction + "
                  "first coarse sweep): n*(1 B row type + x + f + smoothed u) + n_H*(f_H + u_H + coarse diagonal)")
     elif lay_name == "dict":
@@ -262,6 +291,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", dest="n", type=int, default=4096, help="grid points per direction")
+    ap.add_argument("--dim", type=int, default=2, choices=[2, 3],
+                    help="2: Grid::laplacian (5-point); 3: the 7-point analogue (BASELINE config 5)")
     ap.add_argument("--levels", type=int, default=0, help="0 = coarsest <= 511 dofs")
     ap.add_argument("--omega", type=float, default=0.6,
                     help="Jacobi relaxation; must stay below 2/lambda_max(D^-1 A) ~ 0.67 on the "
@@ -290,12 +321,18 @@ def main():
                     help="grid of the CPU baseline sample (0 = the benchmarked --grid itself)")
     ap.add_argument("--cpu-cycles", type=int, default=3)
     ap.add_argument("--profile-launches", type=int, default=40)
-    ap.add_argument("--comm", choices=["safe", "auto", "p2p", "slab", "ipc", "graph"], default="safe",
+    ap.add_argument("--window-levels", type=int, default=-1,
+                    help="window sharding: number of distributed levels (-1 = every level of at least "
+                         "--window-min-rows rows whose halo overhead stays below 35 %% of a block)")
+    ap.add_argument("--window-min-rows", type=int, default=500000)
+    ap.add_argument("--comm", choices=["safe", "auto", "p2p", "slab", "window", "ipc", "graph"], default="safe",
                     help="multi-GPU halo exchange.  safe (default) = the configurations built on "
                          "plain RCCL calls only: replicated (nothing distributed: timed first, it is "
                          "the reference every other one must reproduce), p2p (a send/recv before every "
                          "sweep, residual and transfer) and slab (K-Patch levels over each rank's grid "
-                         "lines + redundant halo: one grouped send/recv and one all-gather per cycle); "
+                         "lines + redundant halo: one grouped send/recv and one all-gather per cycle) and "
+                         "window (every rank sets up and stores only its window of the distributed levels; "
+                         "the only sharded form of --smoother multicolor and --dim 3); "
                          "the fastest one is reported.  auto = additionally "
                          "ipc (hipIpc pushes + stream memory ops) and graph (pushes + flags as "
                          "kernels, one hipGraph per rank): experimental, never run on real xGMI "

@@ -422,12 +422,22 @@ amg_hip_status amg_hip_level_op(amg_hip_solver* s, int32_t level, int32_t op);
 amg_hip_status amg_hip_cycle_bytes(const amg_hip_solver* s, double* cycle_bytes,
                                    double* fine_sweep_bytes);
 
+/* Bytes the launches of ONE V-cycle have to move: for every launch what that kernel reads and
+ * writes once in the layout it really streams (dictionary: 1 B row type per row; K-Patch leg:
+ * 25 n + 24 n_H down, 25 n + 8 n_H up; SELL / CSR: indices + values; vectors 8 B per entry),
+ * summed while the cycle is enqueued.  part 0 = the whole cycle (bench.py divides it by the
+ * measured time per cycle: the whole-cycle fraction of the HBM roof), 1 / 2 / 3 = the parts of
+ * amg_hip_slab_run / amg_hip_window_run once they have run.                                  */
+amg_hip_status amg_hip_cycle_must_move(amg_hip_solver* s, int32_t part, double* bytes);
+
 /* Measurement hook for bench.py: launches the level-0 smoother sweep kernel
  * (the dominant kernel of a V-cycle) n_launches times back to back on the
  * solver's own stream, each launch bracketed by a pair of HIP events on that
  * stream, and returns the average / minimum launch duration in milliseconds.
- * Only for AMG_HIP_SM_JACOBI (one launch = one sweep over level 0); the level-0
- * solution is restored afterwards.                                            */
+ * AMG_HIP_SM_JACOBI: one launch = one sweep over level 0 (K-Patch: the level's down-leg);
+ * AMG_HIP_SM_MULTICOLOR_GS: the first launch of the symmetric pass (K-Patch form: two colour
+ * stages over the level; colour kernels: colour 0).  The level-0 solution is restored
+ * afterwards.                                                                  */
 amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
                                           double* avg_ms, double* min_ms);
 /* Name of the kernel amg_hip_profile_fine_sweep times (as rocprofv3 prints it, without the

@@ -17,6 +17,8 @@ def test_metric_string_and_level_choice():
     assert "N=4096^2" in bench.metric_string(4096)
     assert "N=2048^2" in bench.metric_string(2048)          # was hard-coded
     assert bench.n_levels_for(4096) == 16 and bench.n_levels_for(1024) == 12
+    assert "3D" in bench.metric_string(512, 3) and "N=512^3" in bench.metric_string(512, 3)
+    assert bench.n_levels_for(512, dim=3) == 19             # BASELINE config 5: 134 M -> 511 dofs
     assert bench.HBM_PEAK_GBS == 8000.0
     assert len(bench.CPU_FLAGS) == 2 and "-O3 -march=native" in bench.CPU_FLAGS[1]
 
@@ -68,4 +70,4 @@ def test_multi_gpu_default_is_the_safe_transport_set():
     finally:
         sys.argv = argv
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert 'choices=["safe", "auto", "p2p", "slab", "ipc", "graph"], default="safe"' in src
+    assert 'choices=["safe", "auto", "p2p", "slab", "window", "ipc", "graph"], default="safe"' in src

@@ -1,0 +1,161 @@
+"""Window sharding on the device (include/amg_hip.h "window sharding", window_vcycle.py): every
+rank = one thread of this process with its own stream, its own WINDOW solver
+(amg_hip_create_poisson_window: generator, Galerkin chain, dictionary coding of the window only)
+and its own copy of the replicated tail; the two exchanges per cycle go through
+tests/window_engine.ThreadComm (device copies, what RCCL does between GPUs).  Bar: the assembled
+level-0 solution equals the ordinary single-GPU V-cycle of the whole problem BIT FOR BIT -- true
+Jacobi in 2-D (K-Patch legs over line ranges, and the general kernels) and 3-D, multicolour
+Gauss-Seidel (BASELINE config 4's smoother) -- incl. 8 ranks at 8192^2 multicolour and at 256^3
+exactly as bench.py --gpus 8 cuts them.  True Jacobi / multicolour GS / 3-D have no counterpart
+in the reference: pinned to the oracle twin through the single-GPU cycle's own parity tests
+(tests/test_gpu_parity.py, tests/test_gpu_round2.py).  Nothing here reads /root/reference."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (os.path.join(ROOT, "algebraic-multigrid_amd"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+JAC, MC = 3, 4
+
+
+@pytest.fixture()
+def patch_everywhere(amg):
+    amg.set_patch_min_rows(0)      # K-Patch on every level whose geometry allows it
+    yield
+    amg.set_patch_min_rows(1 << 20)
+
+
+def _sharded(amg, dim, n, L, k, world, smoother, iters, omega, cycles):
+    import window_vcycle as W
+    from window_engine import ThreadComm, run_threads
+    dev = torch.device("cuda", 0)
+
+    def fn(rank, hub):
+        torch.cuda.set_device(dev)
+        st = torch.cuda.Stream(dev)
+        torch.cuda.set_stream(st)
+        plan = W.WindowPlan(dim, n, rank, world, k, smoother, iters)
+        eng = W.HipWindowEngine(amg, dev, st, plan, omega)
+        dv = W.WindowVcycle(eng, plan, ThreadComm(hub, rank, sync=st.synchronize), L)
+        rss = []
+        for _ in range(cycles):
+            dv.vcycle()
+            rss.append(dv.rss())
+        u = dv.gather_solution() if rank == 0 else None
+        if rank != 0:
+            dv.gather_solution()
+        chk = dv.solution_checksum()
+        rows = [eng.mg.get_n_dofs(l) for l in range(k + 1)]
+        dv.close()
+        return u, rss, chk, rows
+    return run_threads(world, fn)
+
+
+def _single(amg, dim, n, L, smoother, iters, omega, cycles):
+    sm = amg.SM_JACOBI if smoother == JAC else amg.SM_MULTICOLOR_GS
+    mg = amg.Multigrid.poisson(n, L, dim=dim, smoother=sm, smoother_iters=iters, omega=omega)
+    rss = []
+    for _ in range(cycles):
+        mg.vcycle()
+        rss.append(mg.rss())
+    u = mg.get_soln(0)
+    n0 = mg.get_n_dofs(0)
+    mg.close()
+    return u, rss, n0
+
+
+def _check(amg, dim, n, L, k, world, smoother, iters, omega, cycles=3):
+    res = _sharded(amg, dim, n, L, k, world, smoother, iters, omega, cycles)
+    u_ref, rss_ref, n0 = _single(amg, dim, n, L, smoother, iters, omega, cycles)
+    u = res[0][0]
+    assert np.array_equal(u, u_ref)
+    chk_ref = int(np.ascontiguousarray(u_ref).view(np.int64).sum(dtype=np.int64))
+    for _, rss, chk, rows in res:
+        assert chk == chk_ref
+        assert rows[0] < n0 or world == 1                  # each rank holds a window only
+        for a, b in zip(rss, rss_ref):
+            assert abs(a - b) <= 1e-12 * b
+    return res
+
+
+@pytest.mark.parametrize("world,k", [(2, 3), (3, 2), (5, 1)])
+def test_window_jacobi_2d_patch_legs(amg, patch_everywhere, world, k):
+    _check(amg, 2, 1024, 10, k, world, JAC, 2, 0.6)
+
+
+def test_window_jacobi_2d_general_kernels(amg):
+    # default K-Patch threshold (2^20 rows): the windows' levels take the dictionary kernels,
+    # the fused pair kernels and the separate transfers
+    _check(amg, 2, 512, 8, 3, 2, JAC, 2, 0.6)
+
+
+def test_window_jacobi_odd_sweeps(amg):
+    _check(amg, 2, 512, 8, 2, 3, JAC, 3, 0.5, cycles=2)
+
+
+@pytest.mark.parametrize("world,k", [(2, 2), (3, 3)])
+def test_window_multicolor_2d(amg, patch_everywhere, world, k):
+    _check(amg, 2, 1024, 10, k, world, MC, 1, 1.0)
+
+
+def test_window_multicolor_2d_against_oracle(amg, oracle):
+    """the sharded product against the ORACLE twin replaying the product's global colours"""
+    n, L, k, world, cycles = 256, 8, 2, 2, 3
+    res = _sharded(amg, 2, n, L, k, world, MC, 1, 1.0, cycles)
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_MULTICOLOR, smoother_iters=1, omega=1.0)
+    h = amg.Multigrid(A.colptr, A.rowind, A.val, b, L, smoother=amg.SM_MULTICOLOR_GS, host_only=True)
+    for l in range(L):
+        c, nc = h.get_colors(l)
+        ref.set_colors(l, c, nc)
+    h.close()
+    for _ in range(cycles):
+        ref.vcycle()
+    assert np.array_equal(res[0][0], ref.get_vec(0, "u"))
+
+
+@pytest.mark.parametrize("world,k", [(2, 2), (4, 1)])
+def test_window_jacobi_3d(amg, world, k):
+    _check(amg, 3, 64, 8, k, world, JAC, 2, 0.6)
+
+
+def test_window_jacobi_3d_against_oracle(amg, oracle):
+    n, L, k, world, cycles = 32, 6, 2, 2, 2
+    res = _sharded(amg, 3, n, L, k, world, JAC, 2, 0.6, cycles)
+    ref = oracle.Multigrid(oracle.laplacian(n, 3), oracle.rhs(n, 3), L, smoother=oracle.SM_TRUE_JACOBI,
+                           smoother_iters=2, omega=0.6)
+    for _ in range(cycles):
+        ref.vcycle()
+    assert np.array_equal(res[0][0], ref.get_vec(0, "u"))
+
+
+def test_window_solver_refuses_whole_cycles(amg):
+    mg = amg.Multigrid.poisson_window(256, 32, 128, 3)
+    with pytest.raises((amg.AmgHipError, ValueError)):
+        mg.vcycle()
+    with pytest.raises((amg.AmgHipError, ValueError)):
+        mg.slab_setup(0, 2)
+    mg.window_run(1)
+    mg.window_run(3)
+    mg.sync()
+    mg.close()
+
+
+# ---- full size, cut exactly as bench.py --gpus 8 cuts them ---------------------------------
+def test_window_full_size_config4_8192_multicolor_eight_ranks(amg):
+    """BASELINE config 4: 8192^2, multicolour GS, 8 row blocks (1024 lines + 47 halo lines each)."""
+    _check(amg, 2, 8192, 18, 3, 8, MC, 1, 1.0, cycles=2)
+
+
+def test_window_full_size_config5_256cubed_eight_ranks(amg):
+    """BASELINE config 5's shape at 256^3 (512^3 needs more than one GPU's worth of windows in
+    this one-process emulation): 8 blocks of 32 x-y planes + 11 halo planes."""
+    _check(amg, 3, 256, 14, 2, 8, JAC, 2, 0.6, cycles=2)
