@@ -55,6 +55,13 @@ class SlabInfo(C.Structure):
                 ("u0", C.c_void_p), ("f_gather", C.c_void_p)]
 
 
+class WindowPlanC(C.Structure):
+    """amg_hip_window_plan (include/amg_hip.h)"""
+    _fields_ = [(k, C.c_int64) for k in ("own0_off", "own0_end", "send_prev_cnt", "recv_prev_cnt",
+                                         "send_next_cnt", "recv_next_cnt", "own_k_off", "own_k_cnt",
+                                         "block_k", "uk_off")]
+
+
 class HaloDesc(C.Structure):
     _fields_ = [("dst_prev", C.c_void_p), ("src_prev", C.c_void_p), ("bytes_prev", C.c_int64),
                 ("dst_next", C.c_void_p), ("src_next", C.c_void_p), ("bytes_next", C.c_int64),
@@ -132,6 +139,17 @@ _SIGS = {
     "amg_hip_window_setup": (C.c_int, [C.c_void_p, _i64p, _i64p, _i64p, _i64p]),
     "amg_hip_window_run": (C.c_int, [C.c_void_p, C.c_int32]),
     "amg_hip_vec_dev_ptr": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), _i64p]),
+    "amg_hip_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "amg_hip_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "amg_hip_comm_create": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "amg_hip_comm_destroy": (None, [C.c_void_p]),
+    "amg_hip_comm_rank": (C.c_int32, [C.c_void_p]),
+    "amg_hip_comm_world": (C.c_int32, [C.c_void_p]),
+    "amg_hip_comm_neighbor_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "amg_hip_comm_all_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "amg_hip_slab_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SlabInfo)]),
+    "amg_hip_window_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(WindowPlanC)]),
     "amg_hip_level_layout": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "amg_hip_get_colors": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p]),
     "amg_hip_level_op": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
@@ -264,6 +282,36 @@ def dict_probe(rowptr, col, val, ncols, diag_shift=0):
         return None
     _chk(st)
     return a.value, b.value, c.value
+
+
+class Comm:
+    """amg_hip_comm: the library's own RCCL communicator (include/amg_hip.h "communicator").
+    id_bytes: the 128 bytes rank 0 got from Comm.unique_id(), handed to every rank by the caller."""
+
+    def __init__(self, id_bytes, rank, world, device=-1):
+        h = C.c_void_p()
+        _chk(lib().amg_hip_comm_create(bytes(id_bytes), int(rank), int(world), int(device), C.byref(h)))
+        self._h, self.rank, self.world = h, rank, world
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _chk(lib().amg_hip_comm_unique_id(buf))
+        return buf.raw
+
+    def slab_cycle(self, mg, info):
+        _chk(lib().amg_hip_slab_cycle(mg._h, self._h, C.byref(info)))
+
+    def window_cycle(self, window_mg, tail_mg, plan_c):
+        _chk(lib().amg_hip_window_cycle(window_mg._h, tail_mg._h, self._h, C.byref(plan_c)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().amg_hip_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 def slab_plan(lines, rank, world, levels):

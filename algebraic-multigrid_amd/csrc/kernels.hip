@@ -953,6 +953,9 @@ struct PatchCells {
 //   utabi: per type rmask (slots in use), corners (1 when a corner slot 0, 2, 6, 8 is in use)
 struct PatchU {
   double wj[9], wr[9], diag;
+#ifdef AMG_PATCH_FASTDIV
+  double rdiag;
+#endif
   uint32_t rmask, corners;
 };
 __device__ __forceinline__ void patch_load_u(PatchU& U, uint32_t tu, const double* __restrict__ utabd,
@@ -965,6 +968,9 @@ __device__ __forceinline__ void patch_load_u(PatchU& U, uint32_t tu, const doubl
     U.wr[e] = d[9 + e];
   }
   U.diag = d[18];
+#ifdef AMG_PATCH_FASTDIV
+  U.rdiag = 1.0 / (U.diag == 0.0 ? 1.0 : U.diag);
+#endif
   U.rmask = (uint32_t)i[0];
   U.corners = (uint32_t)i[1];
 }
@@ -973,11 +979,25 @@ __device__ __forceinline__ void patch_load_u(PatchU& U, uint32_t tu, const doubl
 // have weight +0.0: adding (+0.0) x leaves a Jacobi accumulator's bits alone for finite x (see
 // dict_rows); the residual selects them away.  CORNERS = false: the four corner slots are
 // not even read (5-point level).
-template <bool RESID, bool CORNERS, bool GS = false>
+// MASK >= 0: the type's slots in use are exactly MASK (the interior row types of a Poisson
+// hierarchy: 0x0BA = 5-point level 0, 0x1D7 = level 1 with its exact-zero +-1 entries pruned,
+// 0x1FF = 9-point levels): absent slots are not even multiplied, and the residual needs no
+// selects.  Same bits as the generic form (MASK < 0): a Jacobi accumulator starts at +0.0 and
+// never becomes -0.0, so skipping a (+0.0) x term changes nothing for finite x; the residual's
+// generic form selects absent terms away, which is what not computing them does.
+template <bool RESID, bool CORNERS, bool GS = false, int MASK = -1>
 __device__ __forceinline__ void patch_eval_u(const double* buf, int cell0, const PatchU& U,
                                              const double (&f)[PATCH_K], double omega,
                                              double (&res)[PATCH_K]) {
   const double* p = buf + cell0 - PATCH_EC;  // line above the first cell
+  if (!RESID && U.diag == 0.0) {  // rows without a diagonal keep their value (smoother.hpp:133)
+#pragma unroll
+    for (int k = 0; k < PATCH_K; ++k) res[k] = p[(k + 1) * PATCH_EC];
+    return;
+  }
+  // (the test above is wave-uniform and sits OUTSIDE the cell loop: inside it, it cut the loop
+  // into one basic block per cell and the eight independent dependency chains -- LDS read, sums,
+  // IEEE division -- ran one after the other instead of interleaved)
   double w[3][3];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
@@ -999,9 +1019,13 @@ __device__ __forceinline__ void patch_eval_u(const double* buf, int cell0, const
       for (int s9 = 0; s9 < 9; ++s9) {
         const int r = s9 / 3, c = s9 % 3;
         if (!CORNERS && r != 1 && c != 1) continue;
-        double t = U.wr[s9] * w[r][c];
-        t = ((U.rmask >> s9) & 1u) ? t : 0.0;
-        acc -= t;
+        if (MASK >= 0) {
+          if ((MASK >> s9) & 1) acc -= U.wr[s9] * w[r][c];
+        } else {
+          double t = U.wr[s9] * w[r][c];
+          t = ((U.rmask >> s9) & 1u) ? t : 0.0;
+          acc -= t;
+        }
       }
       res[k] = acc;
     } else {
@@ -1010,12 +1034,21 @@ __device__ __forceinline__ void patch_eval_u(const double* buf, int cell0, const
       for (int s9 = 0; s9 < 9; ++s9) {
         const int r = s9 / 3, c = s9 % 3;
         if (s9 == 4 || (!CORNERS && r != 1 && c != 1)) continue;
+        if (MASK >= 0 && !((MASK >> s9) & 1)) continue;
         acc += U.wj[s9] * w[r][c];
       }
-      if (U.diag == 0.0) {
-        res[k] = xi;
-      } else {
+      {
+#ifdef AMG_PATCH_FASTDIV
+        // experiment: Markstein's correctly rounded quotient from the (wave-uniform) reciprocal
+        const double nm = f[k] - acc;
+        const double q0 = nm * U.rdiag;
+        const double r0 = __builtin_fma(-U.diag, q0, nm);
+        const double q1 = __builtin_fma(r0, U.rdiag, q0);
+        const double r1 = __builtin_fma(-U.diag, q1, nm);
+        const double q = __builtin_fma(r1, U.rdiag, q1);
+#else
         const double q = (f[k] - acc) / U.diag;  // smoother.hpp:136
+#endif
         res[k] = GS ? q : xi + omega * (q - xi);      // GS: the Gauss-Seidel update itself (K-SELL CSR_GS)
       }
     }
@@ -1024,9 +1057,11 @@ __device__ __forceinline__ void patch_eval_u(const double* buf, int cell0, const
       w[0][c] = w[1][c];
       w[1][c] = w[2][c];
     }
+    // 9-point rows: keep the cells apart (interleaving them costs more registers than the 72 that
+    // four workgroups per CU leave: measured slower on levels 1-3); 5-point rows interleave
+    if (CORNERS) __builtin_amdgcn_sched_barrier(0);
   }
 }
-
 // Row arithmetic of dict_rows, per-lane table entries from the LDS copy (mixed row types:
 // level boundaries).
 template <int UN, bool RESID, bool GS = false>
@@ -1080,7 +1115,7 @@ __device__ __forceinline__ double patch_eval(const double* buf, int cell, uint32
 // latency-bound stages need).  Cells outside the region or outside the matrix keep their
 // value; ZERO: such cells inside the region are set to 0.0 instead (the residual that the
 // restriction reads).  out (optional): rows of the patch proper also go to global memory.
-template <int UN, bool RESID, bool NT, bool ZERO>
+template <int UN, int UM, bool RESID, bool NT, bool ZERO>
 __device__ __forceinline__ void patch_stage(const PatchCells& pc, int m, int ntypes, double* buf,
                                             const PatchU& U, const PatchJ* tabJ, const PatchR* tabR,
                                             double omega, int l0, int l1, int c0, int c1, double* out) {
@@ -1093,11 +1128,12 @@ __device__ __forceinline__ void patch_stage(const PatchCells& pc, int m, int nty
     inr[k] = inc && lj >= l0 && lj < l1;
     did[k] = inr[k] && pc.live[k];
   }
-  if (pc.uniform) {
-    // interior of the level: one row type for the whole wave; cells outside the region are
-    // evaluated with it too (their reads stay inside the guard lines) and dropped
-    if (U.corners) patch_eval_u<RESID, true>(buf, pc.cell0, U, pc.f, omega, res);
-    else patch_eval_u<RESID, false>(buf, pc.cell0, U, pc.f, omega, res);
+  if (pc.uniform && U.rmask == (uint32_t)UM) {
+    // interior of the level (UM = the slots its row type uses, chosen at launch): one row type
+    // for the whole wave, weights in scalar registers; cells outside the region are evaluated
+    // with it too (their reads stay inside the guard lines) and dropped.  Every other wave
+    // (level boundaries) takes the per-lane table.
+    patch_eval_u<RESID, (UM & 0x145) != 0, false, UM>(buf, pc.cell0, U, pc.f, omega, res);
   } else {
 #pragma unroll
     for (int k = 0; k < PATCH_K; ++k)
@@ -1269,7 +1305,7 @@ __device__ __forceinline__ void patch_prologue(const PatchCells& pc, double* buf
 
 // FIRST: the input is the level's u and both pre-sweeps run here (level 0); else the input
 // is the result of the first sweep (done by the finer level's kernel) and one sweep runs.
-template <int UN, bool FIRST, bool NT>
+template <int UN, int UM, bool FIRST, bool NT>
 __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
@@ -1290,16 +1326,16 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
   patch_prologue(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U);
   lds_barrier();
   if (FIRST) {
-    patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -2, PATCH_TH + 2, -2,
+    patch_stage<UN, UM, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -2, PATCH_TH + 2, -2,
                                       PATCH_TW + 3, nullptr);
     lds_barrier();
   }
-  patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
+  patch_stage<UN, UM, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
                                     PATCH_TW + 2, nullptr);
   lds_barrier();
   patch_copy_out<NT>(buf, u_out, n, m, j0, i0);  // the residual stage below only reads until its barrier
   // residual; rows outside the matrix read as 0.0 for the restriction (ZERO)
-  patch_stage<UN, true, NT, true>(pc, m, ntypes, buf, U, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW + 1,
+  patch_stage<UN, UM, true, NT, true>(pc, m, ntypes, buf, U, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW + 1,
                                   r_out);
   lds_barrier();
   const double* rsb = buf;
@@ -1321,7 +1357,7 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
   }
 }
 
-template <int UN, bool NT>
+template <int UN, int UM, bool NT>
 __global__ __launch_bounds__(PATCH_NT, 7) void patch_up_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
@@ -1340,10 +1376,10 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_up_kernel(
   else patch_load<true, false>(pc, tf, n, m, j0, i0, x, f, rtype, ntypes, uH, nH, buf);
   patch_prologue(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U);
   lds_barrier();
-  patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
+  patch_stage<UN, UM, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
                                     PATCH_TW + 1, nullptr);
   lds_barrier();
-  patch_stage<UN, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW,
+  patch_stage<UN, UM, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW,
                                     nullptr);
   lds_barrier();
   patch_copy_out<NT>(buf, u_out, n, m, j0, i0);
@@ -1353,7 +1389,7 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_up_kernel(
 // One colour of a Gauss-Seidel half-sweep as a patch stage: cells of colour `cpar` inside the
 // region take (f - sum of off-diagonal terms) / diagonal from the CURRENT neighbours (which all
 // have the other colour), every other cell keeps its value.  parbits: bit k = colour of cell k.
-template <int UN>
+template <int UN, int UM>
 __device__ __forceinline__ void patch_stage_color(const PatchCells& pc, int ntypes, double* buf,
                                                   const PatchU& U, const PatchJ* tabJ, const PatchR* tabR,
                                                   int l0, int l1, int c0, int c1, uint32_t parbits,
@@ -1366,9 +1402,8 @@ __device__ __forceinline__ void patch_stage_color(const PatchCells& pc, int ntyp
     const int lj = pc.lj0 + k;
     did[k] = inc && lj >= l0 && lj < l1 && pc.live[k] && ((parbits >> k) & 1u) == cpar;
   }
-  if (pc.uniform) {
-    if (U.corners) patch_eval_u<false, true, true>(buf, pc.cell0, U, pc.f, 1.0, res);
-    else patch_eval_u<false, false, true>(buf, pc.cell0, U, pc.f, 1.0, res);
+  if (pc.uniform && U.rmask == (uint32_t)UM) {
+    patch_eval_u<false, (UM & 0x145) != 0, true, UM>(buf, pc.cell0, U, pc.f, 1.0, res);
   } else {
 #pragma unroll
     for (int k = 0; k < PATCH_K; ++k)
@@ -1389,7 +1424,7 @@ __device__ __forceinline__ void patch_stage_color(const PatchCells& pc, int ntyp
 // colour(row) = ((row / m + row % m) & 1) ^ cb (the checkerboard the greedy colouring yields on
 // the 5-point level; verified on the host).  Same row arithmetic as the colour kernels
 // (dict_rows<CSR_GS>): ascending-column sum of the off-diagonal terms, IEEE divide.
-template <int UN, bool NT, bool PROLONG, bool TAIL>
+template <int UN, int UM, bool NT, bool PROLONG, bool TAIL>
 __global__ __launch_bounds__(PATCH_NT, 7) void patch_rb_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi, int nent, int ntypes,
@@ -1417,15 +1452,15 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_rb_kernel(
   }
   lds_barrier();
   constexpr int E = TAIL ? 1 : 0;  // the residual stage needs one more ring
-  patch_stage_color<UN>(pc, ntypes, buf, U, tabJ, tabR, -1 - E, PATCH_TH + 1 + E, -1 - E,
+  patch_stage_color<UN, UM>(pc, ntypes, buf, U, tabJ, tabR, -1 - E, PATCH_TH + 1 + E, -1 - E,
                         PATCH_TW + 1 + 2 * E, parbits, c_first & 1u);
   lds_barrier();
-  patch_stage_color<UN>(pc, ntypes, buf, U, tabJ, tabR, -E, PATCH_TH + E, -E, PATCH_TW + 2 * E, parbits,
+  patch_stage_color<UN, UM>(pc, ntypes, buf, U, tabJ, tabR, -E, PATCH_TH + E, -E, PATCH_TW + 2 * E, parbits,
                         (c_first & 1u) ^ 1u);
   lds_barrier();
   patch_copy_out<NT>(buf, u_out, n, m, j0, i0);
   if (TAIL) {
-    patch_stage<UN, true, NT, true>(pc, m, ntypes, buf, U, tabJ, tabR, 1.0, 0, PATCH_TH, 0, PATCH_TW + 1,
+    patch_stage<UN, UM, true, NT, true>(pc, m, ntypes, buf, U, tabJ, tabR, 1.0, 0, PATCH_TH, 0, PATCH_TW + 1,
                                     r_out);
     lds_barrier();
     for (int q = threadIdx.x; q < PATCH_TH * (PATCH_TW / 2); q += PATCH_NT) {
@@ -1459,16 +1494,23 @@ static unsigned patch_grid(int64_t n, int64_t m, int64_t line_lo, int64_t line_h
   return (unsigned)(((line_hi + PATCH_TH - 1) / PATCH_TH - *py0) * *px_count);
 }
 int patch_tile_lines() { return PATCH_TH; }
+// kernel kinds: (row width of the per-lane path, slots of the interior row type -- the scalar path)
+//   (5, 0x0BA) the 5-point level 0; (7, 0x1D7) / (9, 0x1D7) level 1, whose +-1 entries are exact
+//   zeros and pruned (its line ends keep rows of 9); (9, 0x1FF) the 9-point levels
+int patch_default_umask(int un) { return un <= 5 ? 0x0BA : (un <= 7 ? 0x1D7 : 0x1FF); }
+// the mask of the kernel kind patch_dispatch picks for (un, umask)
+int patch_kind_umask(int un, int umask) { return (un > 7 && un <= 9 && umask == 0x1D7) ? 0x1D7 : patch_default_umask(un); }
 template <class F>
-static hipError_t patch_dispatch(int un, bool nt, F&& go) {
+static hipError_t patch_dispatch(int un, int umask, bool nt, F&& go) {
   using std::integral_constant;
-  auto with_nt = [&](auto U) {
-    if (nt) go(U, integral_constant<bool, true>{});
-    else go(U, integral_constant<bool, false>{});
+  auto with_nt = [&](auto U, auto M) {
+    if (nt) go(U, M, integral_constant<bool, true>{});
+    else go(U, M, integral_constant<bool, false>{});
   };
-  if (un <= 5) with_nt(integral_constant<int, 5>{});
-  else if (un <= 7) with_nt(integral_constant<int, 7>{});
-  else if (un <= 9) with_nt(integral_constant<int, 9>{});
+  if (un <= 5) with_nt(integral_constant<int, 5>{}, integral_constant<int, 0x0BA>{});
+  else if (un <= 7) with_nt(integral_constant<int, 7>{}, integral_constant<int, 0x1D7>{});
+  else if (un <= 9 && umask == 0x1D7) with_nt(integral_constant<int, 9>{}, integral_constant<int, 0x1D7>{});
+  else if (un <= 9) with_nt(integral_constant<int, 9>{}, integral_constant<int, 0x1FF>{});
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -1483,13 +1525,13 @@ hipError_t launch_patch_down(bool first, int64_t n, int64_t m, const PatchRef& P
   const unsigned grid = patch_grid(n, m, line_lo, line_hi, &pxc, &py0);
   if (grid == 0) return hipSuccess;
   const int xm = g_xcd_map ? 1 : 0;  // halo lines of neighbouring patches meet in one L2
-  return patch_dispatch(P.un, P.nt != 0, [&](auto U, auto NTF) {
+  return patch_dispatch(P.un, P.umask, P.nt != 0, [&](auto U, auto M, auto NTF) {
     if (first)
-      hipLaunchKernelGGL((patch_down_kernel<decltype(U)::value, true, decltype(NTF)::value>), dim3(grid),
+      hipLaunchKernelGGL((patch_down_kernel<decltype(U)::value, decltype(M)::value, true, decltype(NTF)::value>), dim3(grid),
                          dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, u_out,
                          r_out, (int)nH, fH, diagH, uH1, omega, xm, py0, P.tflag);
     else
-      hipLaunchKernelGGL((patch_down_kernel<decltype(U)::value, false, decltype(NTF)::value>), dim3(grid),
+      hipLaunchKernelGGL((patch_down_kernel<decltype(U)::value, decltype(M)::value, false, decltype(NTF)::value>), dim3(grid),
                          dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, u_out,
                          r_out, (int)nH, fH, diagH, uH1, omega, xm, py0, P.tflag);
   });
@@ -1504,8 +1546,8 @@ hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double
   const unsigned grid = patch_grid(n, m, line_lo, line_hi, &pxc, &py0);
   if (grid == 0) return hipSuccess;
   const int xm = g_xcd_map ? 1 : 0;  // halo lines of neighbouring patches meet in one L2
-  return patch_dispatch(P.un, P.nt != 0, [&](auto U, auto NTF) {
-    hipLaunchKernelGGL((patch_up_kernel<decltype(U)::value, decltype(NTF)::value>), dim3(grid),
+  return patch_dispatch(P.un, P.umask, P.nt != 0, [&](auto U, auto M, auto NTF) {
+    hipLaunchKernelGGL((patch_up_kernel<decltype(U)::value, decltype(M)::value, decltype(NTF)::value>), dim3(grid),
                        dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, uH,
                        (int)nH, u_out, omega, xm, py0, P.tflag);
   });
@@ -1521,9 +1563,9 @@ hipError_t launch_patch_rb(bool prolong, bool tail, int64_t n, int64_t m, const 
   const unsigned grid = patch_grid(n, m, line_lo, line_hi, &pxc, &py0);
   if (grid == 0) return hipSuccess;
   const int xm = g_xcd_map ? 1 : 0;
-  return patch_dispatch(P.un, P.nt != 0, [&](auto U, auto NTF) {
+  return patch_dispatch(P.un, P.umask, P.nt != 0, [&](auto U, auto M, auto NTF) {
 #define AMG_RB(PRO, TL)                                                                              \
-  hipLaunchKernelGGL((patch_rb_kernel<decltype(U)::value, decltype(NTF)::value, PRO, TL>), dim3(grid), \
+  hipLaunchKernelGGL((patch_rb_kernel<decltype(U)::value, decltype(M)::value, decltype(NTF)::value, PRO, TL>), dim3(grid), \
                      dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi,    \
                      P.nent, P.ntypes, x, f, uH, (int)nH, u_out, r_out, fH, uH_zero, (uint32_t)c_first,  \
                      (uint32_t)cb, xm, py0, P.tflag)
@@ -2953,25 +2995,46 @@ __device__ __forceinline__ void band_chain_fetch(ChainChunk<W>& c, const double*
     c.r[i] = rv[i];
   }
 }
+// One chunk of CHAIN_CH steps of y_i = ((r_i - o[i][0] y_{i-W}) - ...) - o[i][W-1] y_{i-1} (ascending
+// distance order: the row-oriented substitution's).  Only the LAST product depends on the previous
+// step: a step's critical path is one multiply and one subtract (two dependent fp64 operations,
+// ~11 cycles each on gfx950: tools/fp64_chain.hip).  Everything before that product -- the
+// "early" part r_i - sum_{t < W-1} o[i][t] y_{i-W+t} -- only needs results that are at least two
+// steps old, so the early part of step i+1 is formed while step i's chain is in flight, in a
+// PINNED instruction order (an in-order wave executes what it is given; left to the scheduler
+// the four operations of a step came out as one dependent sequence, 31 ns per step):
+//   m = o[i][W-1] * y_{i-1};  products of early_{i+1};  y_i = early_i - m;  subtractions of early_{i+1}
+// Same operations on the same operands in the same order per row: same bits.
+// nxt: the chunk after c (its first step's early part is formed by c's last step).
 template <int W>
-__device__ __forceinline__ void band_chain_steps(const ChainChunk<W>& c, double (&prev)[W], int lane,
-                                                 int left, double* out) {
+__device__ __forceinline__ void band_chain_steps(const ChainChunk<W>& c, const ChainChunk<W>& nxt,
+                                                 double (&prev)[W], double& early, int lane, double* out) {
   double res[CHAIN_CH];
 #pragma unroll
   for (int i = 0; i < CHAIN_CH; ++i) {
-    double acc = c.r[i];
+    const double m = c.o[i][W - 1] * prev[W - 1];
+    __builtin_amdgcn_sched_barrier(0);
+    const double* on = i + 1 < CHAIN_CH ? c.o[i + 1] : nxt.o[0];
+    double pr[W > 1 ? W - 1 : 1];
 #pragma unroll
-    for (int t = 0; t < W; ++t) acc -= c.o[i][t] * prev[t];
+    for (int t = 0; t + 1 < W; ++t) pr[t] = on[t] * prev[t + 1];   // y_{i+1-W+t} = prev[t + 1]
+    __builtin_amdgcn_sched_barrier(0);
+    const double acc = early - m;
+    __builtin_amdgcn_sched_barrier(0);
+    double en = i + 1 < CHAIN_CH ? c.r[i + 1] : nxt.r[0];
+#pragma unroll
+    for (int t = 0; t + 1 < W; ++t) en -= pr[t];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t + 1 < W; ++t) prev[t] = prev[t + 1];
     prev[W - 1] = acc;
     res[i] = acc;
+    early = en;
   }
   if (lane == 0) {  // every lane holds all eight results; one lane stores them (padded array)
 #pragma unroll
     for (int i = 0; i < CHAIN_CH; ++i) out[i] = res[i];
   }
-  (void)left;
 }
 template <int W>
 __device__ __forceinline__ void band_chain_pass(int n, const double* ops, double* v) {
@@ -2981,6 +3044,9 @@ __device__ __forceinline__ void band_chain_pass(int n, const double* ops, double
   for (int t = 0; t < W; ++t) prev[t] = 0.0;
   ChainChunk<W> A, B;
   band_chain_fetch<W>(A, ops, v);
+  double early = A.r[0];  // step 0: the same subtractions of (operand x 0.0) the plain loop makes
+#pragma unroll
+  for (int t = 0; t + 1 < W; ++t) early -= A.o[0][t] * prev[t];
   for (int s0 = 0; s0 < n; s0 += 2 * CHAIN_CH) {
     const double* op = ops + s0 * W;
     double* rv = v + s0;
@@ -2988,12 +3054,32 @@ __device__ __forceinline__ void band_chain_pass(int n, const double* ops, double
     // there: sched_barrier), so the LDS latency hides behind it
     band_chain_fetch<W>(B, op + CHAIN_CH * W, rv + CHAIN_CH);
     __builtin_amdgcn_sched_barrier(0);
-    band_chain_steps<W>(A, prev, lane, n - s0, rv);
+    band_chain_steps<W>(A, B, prev, early, lane, rv);
     __builtin_amdgcn_sched_barrier(0);
     band_chain_fetch<W>(A, op + 2 * CHAIN_CH * W, rv + 2 * CHAIN_CH);
     __builtin_amdgcn_sched_barrier(0);
-    band_chain_steps<W>(B, prev, lane, n - s0 - CHAIN_CH, rv + CHAIN_CH);
+    band_chain_steps<W>(B, A, prev, early, lane, rv + CHAIN_CH);
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// global -> LDS with the loads of a round issued TOGETHER (one memory round trip per 16 x 64
+// entries; written as a plain loop the compiler waited for every load before the next one:
+// seventeen dependent round trips for the 511-row level, more than the substitution itself)
+__device__ __forceinline__ void band_chain_stage(const double* __restrict__ src, double* dst, int valid,
+                                                 int total, int lane) {
+  constexpr int R = 16;
+  for (int base = 0; base < total; base += 64 * R) {
+    double t[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int k = base + j * 64 + lane;
+      t[j] = k < valid ? src[k] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int k = base + j * 64 + lane;
+      if (k < total) dst[k] = t[j];
+    }
   }
 }
 template <int W>
@@ -3005,8 +3091,14 @@ __global__ __launch_bounds__(64) void band_chain_kernel(
   double* ops = chain_lds;           // np x W
   double* v = chain_lds + np * W;    // np: right-hand side in step order, then the result
   const int lane = threadIdx.x;
-  for (int k = lane; k < np * W; k += 64) ops[k] = k < n * W ? cf[k] : 0.0;
-  for (int s = lane; s < np; s += 64) v[s] = s < n ? f[s] : 0.0;
+  double dgv[32];                    // the diagonal, mirrored, requested before the first pass
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int s = lane + 64 * q;
+    dgv[q] = s < n ? dg[n - 1 - s] : 1.0;
+  }
+  band_chain_stage(cf, ops, n * W, np * W, lane);
+  band_chain_stage(f, v, n, np, lane);
   lds_barrier();
   band_chain_pass<W>(n, ops, v);                 // L y = f
   lds_barrier();
@@ -3014,9 +3106,9 @@ __global__ __launch_bounds__(64) void band_chain_kernel(
 #pragma unroll
   for (int q = 0; q < 32; ++q) {
     const int s = lane + 64 * q;
-    z[q] = s < n ? v[n - 1 - s] / dg[n - 1 - s] : 0.0;
+    z[q] = s < n ? v[n - 1 - s] / dgv[q] : 0.0;
   }
-  for (int k = lane; k < n * W; k += 64) ops[k] = cb[k];
+  band_chain_stage(cb, ops, n * W, n * W, lane);
   lds_barrier();
 #pragma unroll
   for (int q = 0; q < 32; ++q) {

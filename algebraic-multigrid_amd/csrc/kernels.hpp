@@ -99,12 +99,15 @@ struct PatchRef {
   // (launch_patch_tile_flags); null = always take the general path
   const uint8_t* tflag = nullptr;
   int nent = 0, ntypes = 0, un = 0, nt = 0;
+  int umask = 0;  // slots (3 x 3, bit = slot) of the level's interior row type: selects the kernel kind
 };
 // flag == null: only *n_tiles is computed (the size of the array)
 hipError_t launch_patch_tile_flags(int64_t n, int64_t m, const uint8_t* rtype, int ntypes, uint8_t* flag,
                                    int64_t* n_tiles, hipStream_t st);
 bool patch_geometry_ok(int64_t n, int64_t m);
 int patch_un(int longest_row);
+int patch_default_umask(int un);
+int patch_kind_umask(int un, int umask);
 int patch_lds_pitch();
 int patch_max_entries();
 // first: both pre-sweeps (x = u) else the second only (x = result of the first sweep);

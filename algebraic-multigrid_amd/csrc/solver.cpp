@@ -259,7 +259,7 @@ struct DevMat {
   // K-Patch (temporal blocking): per (row type, slot) table, pitch of the band
   bool patch = false;
   int64_t patch_m = 0;
-  int patch_un = 0, patch_ntypes = 0;
+  int patch_un = 0, patch_ntypes = 0, patch_umask = 0;
   DevMem patch_tab, patch_utabd, patch_utabi, patch_flags;
   PatchRef patch_ref() const {
     PatchRef P;
@@ -270,6 +270,7 @@ struct DevMat {
     P.utabi = patch_utabi.as<int32_t>();
     P.ntypes = patch_ntypes;
     P.un = patch_un;
+    P.umask = patch_umask;
     P.nent = patch_ntypes * patch_un;
     P.nt = dict_nt;
     return P;
@@ -452,6 +453,17 @@ hipError_t finish_dict(const DictMat& T, int64_t n, int64_t diag_shift, DevMat* 
       if ((e = launch_patch_tile_flags(n, D->patch_m, D->drtype.as<uint8_t>(), nty,
                                        D->patch_flags.as<uint8_t>(), nullptr, nullptr)) != hipSuccess) return e;
       if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+      // the interior row type = the type most tiles consist of; its slots choose the kernel kind
+      {
+        std::vector<uint8_t> fl((size_t)tiles);
+        if ((e = hipMemcpy(fl.data(), D->patch_flags.p, fl.size(), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        std::vector<int64_t> cnt(256, 0);
+        for (uint8_t f : fl) ++cnt[f];
+        int best = -1;
+        for (int t = 0; t < nty; ++t)
+          if (cnt[t] > 0 && (best < 0 || cnt[t] > cnt[best])) best = t;
+        D->patch_umask = best >= 0 ? ui[(size_t)best * 2] : patch_default_umask(patch_un(un));
+      }
       D->patch = true;
     }
   }
@@ -1983,6 +1995,11 @@ amg_hip_status need_device() {
 
 }  // namespace
 
+namespace amg_hip {
+// for the other translation units of the library (comm.cpp): sets amg_hip_last_error
+amg_hip_status fail_status(amg_hip_status st, const std::string& msg) { return fail(st, msg); }
+}  // namespace amg_hip
+
 // =============================================================================
 extern "C" {
 
@@ -2315,6 +2332,13 @@ amg_hip_status amg_hip_window_run(amg_hip_solver* s, int32_t part) {
     if (r != AMG_HIP_OK) return r;
   }
   return amg_hip_slab_run(s, part);
+}
+
+amg_hip_status amg_hip_get_stream(amg_hip_solver* s, void** stream) {
+  if (!s || !stream) return fail(AMG_HIP_EINVAL, "bad argument");
+  if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "solver was created with host_only = 1: no device state");
+  *stream = (void*)s->stream;
+  return AMG_HIP_OK;
 }
 
 amg_hip_status amg_hip_vec_dev_ptr(amg_hip_solver* s, int32_t level, int32_t which, void** ptr, int64_t* n) {
@@ -2768,8 +2792,8 @@ amg_hip_status amg_hip_fine_sweep_info(const amg_hip_solver* s, char* name, int3
     // one launch of the symmetric pass: two colour stages over the level (patch form), or one
     // colour of one direction (colour kernels: half the rows)
     if (mc_patch_ok(s, 0)) {
-      std::snprintf(name, (size_t)name_cap, "patch_rb_kernel<%d, %s, false, false>", patch_un(A.patch_un),
-                    A.dict_nt ? "true" : "false");
+      std::snprintf(name, (size_t)name_cap, "patch_rb_kernel<%d, %d, %s, false, false>", patch_un(A.patch_un),
+                    patch_kind_umask(A.patch_un, A.patch_umask), A.dict_nt ? "true" : "false");
       bytes = 25.0 * (double)L.n;
     } else {
       std::snprintf(name, (size_t)name_cap, "%s", L.mc_dict ? "dict_gs_color_kernel" : "sell_kernel<5>");
@@ -2780,8 +2804,8 @@ amg_hip_status amg_hip_fine_sweep_info(const amg_hip_solver* s, char* name, int3
     }
   } else if (A.dict && patch_level_ok(s, 0)) {
     // row types + x + f + smoothed u per fine row; f_H, first coarse sweep, coarse diagonal
-    std::snprintf(name, (size_t)name_cap, "patch_down_kernel<%d, true, %s>", patch_un(A.patch_un),
-                  A.dict_nt ? "true" : "false");
+    std::snprintf(name, (size_t)name_cap, "patch_down_kernel<%d, %d, true, %s>", patch_un(A.patch_un),
+                  patch_kind_umask(A.patch_un, A.patch_umask), A.dict_nt ? "true" : "false");
     sweeps = 2;
     bytes = 25.0 * (double)L.n + 24.0 * (double)s->lv[1].n;
     if (s->slab.levels > 0 && s->slab.world > 1) {  // the tiles this rank's launch covers

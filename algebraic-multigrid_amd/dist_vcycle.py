@@ -1102,6 +1102,44 @@ def bench(args):
         finally:
             dog.disarm()
 
+    # The same two sharded cycles with the exchanges issued by the LIBRARY (amg_hip_slab_cycle /
+    # amg_hip_window_cycle over its own RCCL communicator: one C call per cycle, no Python and no
+    # torch.distributed on the data path).  The unique id travels through torch.distributed.
+    if world > 1 and not rehearsal and args.comm in ("safe", "auto", "slab", "window") and \
+            (("slab" in results and dvs is not None) or ("window" in results and dvw is not None)):
+        stash_line("in-library RCCL exchange hung")
+        dog.arm("library RCCL")
+        libc = None
+        try:
+            if os.environ.get("AMG_DIST_FORCE_HANG") == "rccl":
+                time.sleep(args.comm_timeout + 30)
+            idt = torch.zeros(128, dtype=torch.uint8, device=be.device)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(amg.Comm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            libc = amg.Comm(bytes(idt.cpu().numpy().tobytes()), rank, world, local)
+            for name, d in (("slab", dvs), ("window", dvw)):
+                if name not in results or d is None:
+                    continue
+                d.use_library_comm(libc)
+                res = timed(d)
+                if same_result(res, ref):
+                    results[name + "_rccl"] = res
+                    notes[name + "_rccl"] = "ok"
+                    notes[name + "_rccl_distributed_levels"] = notes.get(name + "_distributed_levels")
+                else:
+                    notes[name + "_rccl"] = "ran but did not reproduce the single-GPU result; discarded"
+                    d.libcomm = None
+        except amg.AmgHipError as ex:
+            notes["library_rccl"] = f"unavailable: {ex.message}"
+        except Exception as ex:   # noqa: BLE001
+            notes["library_rccl"] = f"failed: {type(ex).__name__}: {ex}"
+        try:
+            agree("slab_rccl")
+            agree("window_rccl")
+        finally:
+            dog.disarm()
+
     if dv.n_dist and "p2p" in results and args.comm not in ("p2p", "safe", "slab", "window"):
         stash_line("alternative exchange hung")
         # cheaper exchanges pay off on smaller levels (results do not depend on the
@@ -1162,16 +1200,17 @@ def bench(args):
     roof_whole = None
     if general and best == "replicated":
         whole = dvr
-    if best in ("slab", "window") or (whole is not None and (general or hasattr(whole.tail, "mg"))):
+    best0 = best.replace("_rccl", "")
+    if best0 in ("slab", "window") or (whole is not None and (general or hasattr(whole.tail, "mg"))):
         from bench import fine_sweep_roofline
-        mgw = dvs.eng.mg if best == "slab" else (dvw.eng.mg if best == "window" else
-                                                 (whole.mg if general else whole.tail.mg))
+        mgw = dvs.eng.mg if best0 == "slab" else (dvw.eng.mg if best0 == "window" else
+                                                  (whole.mg if general else whole.tail.mg))
         lay_id, mat_b = mgw.level_layout(0)
         lay_nm = {amg.LAYOUT_CSR: "csr", amg.LAYOUT_SELL: "sell", amg.LAYOUT_DICT: "dict"}[lay_id]
         roof_whole = fine_sweep_roofline(amg, mgw, args, lay_nm, mat_b, mgw.get_n_dofs(0), mgw.cycle_bytes()[1],
                                          launches=max(8, args.profile_launches // 2))
-        roof_whole["note"] = ("per rank: rank 0's lines + halo of the level-0 down-leg (slab sharding)" if best == "slab"
-                              else "per rank: the level-0 launch over rank 0's window (owned units + halo)" if best == "window"
+        roof_whole["note"] = ("per rank: rank 0's lines + halo of the level-0 down-leg (slab sharding)" if best0 == "slab"
+                              else "per rank: the level-0 launch over rank 0's window (owned units + halo)" if best0 == "window"
                               else "per rank: every rank runs the whole cycle (nothing is distributed)")
     out = None
     if rank == 0:

@@ -102,7 +102,16 @@ class SlabVcycle:
         else:
             dist.all_gather_into_tensor(vec[:block * self.world], mine.clone(), group=self.group)
 
+    def use_library_comm(self, libcomm):
+        """one V-cycle = ONE C call (amg_hip_slab_cycle): the two exchanges are the library's own
+        RCCL calls on the solver's stream (amg_ctypes.Comm)"""
+        self.libcomm = libcomm
+
     def vcycle(self):
+        if getattr(self, "libcomm", None) is not None:
+            self.libcomm.slab_cycle(self.eng.mg, self.eng.info)
+            self._cycles_run += 1
+            return
         if self.world == 1:
             self.eng.run(1)
             self.eng.run(2)

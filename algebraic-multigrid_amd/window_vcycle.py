@@ -266,6 +266,22 @@ class WindowVcycle:
         self._stage_in = torch.zeros(self.block, dtype=torch.float64, device=dev)
         self._gathered = torch.zeros(self.block * self.world, dtype=torch.float64, device=dev)
         self._cycles_run = 0
+        self.libcomm = None
+
+    def use_library_comm(self, libcomm):
+        """From now on one V-cycle = ONE C call (amg_hip_window_cycle): the exchanges are the
+        library's own RCCL calls on the solver's stream (amg_ctypes.Comm), nothing returns to
+        Python in between.  Needs the C-ABI engine (HipWindowEngine)."""
+        import amg_ctypes as amg
+        p, k = self.plan, self.plan.k
+        rp, rn, sp, sn = p.halo_sizes()
+        m = p.pitch(0)
+        c = amg.WindowPlanC()
+        c.own0_off, c.own0_end = p.owned_local(0)
+        c.send_prev_cnt, c.recv_prev_cnt, c.send_next_cnt, c.recv_next_cnt = sp * m, rp * m, sn * m, rn * m
+        a, b = p.owned_local(k)
+        c.own_k_off, c.own_k_cnt, c.block_k, c.uk_off = a, b - a, self.block, p.w0 * self.pk
+        self._plan_c, self.libcomm = c, libcomm
 
     # ---- setup: the replicated levels k..L-1 from the all-gathered rows of A_k ----
     def _build_tail(self):
@@ -334,6 +350,10 @@ class WindowVcycle:
 
     def vcycle(self):
         p, e = self.plan, self.eng
+        if self.libcomm is not None:
+            self.libcomm.window_cycle(e.mg, e.tail, self._plan_c)
+            self._cycles_run += 1
+            return
         if self.world > 1:
             self._exchange_u0()
         e.run(1)                                              # multigrid.hpp:265-283, levels < k

@@ -38,7 +38,8 @@ typedef enum {
   AMG_HIP_EINVAL = 1,       /* bad argument (-> std::invalid_argument)        */
   AMG_HIP_EHIP = 2,         /* HIP runtime / device failure                    */
   AMG_HIP_ENOMEM = 3,       /* host or device allocation failed                */
-  AMG_HIP_EUNSUPPORTED = 4  /* valid request this build cannot run on device   */
+  AMG_HIP_EUNSUPPORTED = 4, /* valid request this build cannot run on device   */
+  AMG_HIP_ECOMM = 5         /* RCCL failure (amg_hip_comm_*, the sharded cycles) */
 } amg_hip_status;
 
 /* Smoother plug-ins (smoother.hpp).  0-2 are the reference's three classes;
@@ -325,6 +326,56 @@ amg_hip_status amg_hip_window_run(amg_hip_solver* s, int32_t part);
 /* Device pointer of a level vector (which as in amg_hip_get_vec) for zero-copy exchanges. */
 amg_hip_status amg_hip_vec_dev_ptr(amg_hip_solver* s, int32_t level, int32_t which, void** ptr,
                                    int64_t* n);
+
+/* The stream the solver's work is enqueued on (its own, or opts->stream). */
+amg_hip_status amg_hip_get_stream(amg_hip_solver* s, void** stream);
+
+/* ---- communicator: RCCL from inside the library --------------------------------
+ * The reference is a serial program; this is how a C / C++ caller of the drop-in runs the sharded
+ * V-cycle (multigrid.hpp:263-305 over row blocks) without Python.  librccl.so is opened at run
+ * time (dlopen; AMG_HIP_EUNSUPPORTED when there is none).  Rank 0 calls amg_hip_comm_unique_id
+ * and hands the 128 bytes to every rank by whatever bootstrap the application has (MPI_Bcast,
+ * torch.distributed, a file); every rank then calls amg_hip_comm_create (collective).  One process
+ * per GPU.  The sharded cycles below are ONE call each: everything -- grouped ncclSend / ncclRecv
+ * of the halo, the captured legs, one ncclAllGather, the replicated rest -- is enqueued on the
+ * solver's stream, nothing synchronises with the host.                                        */
+#define AMG_HIP_COMM_ID_BYTES 128
+typedef struct amg_hip_comm amg_hip_comm;
+amg_hip_status amg_hip_comm_unique_id(uint8_t id[AMG_HIP_COMM_ID_BYTES]);
+amg_hip_status amg_hip_comm_create(const uint8_t id[AMG_HIP_COMM_ID_BYTES], int32_t rank, int32_t world,
+                                   int32_t device, amg_hip_comm** out);
+void amg_hip_comm_destroy(amg_hip_comm* c);
+int32_t amg_hip_comm_rank(const amg_hip_comm* c);
+int32_t amg_hip_comm_world(const amg_hip_comm* c);
+/* grouped send / recv with rank-1 and rank+1 (counts in doubles; a null pointer or a zero count
+ * skips that direction); `stream` = hipStream_t                                                */
+amg_hip_status amg_hip_comm_neighbor_exchange(amg_hip_comm* c, const double* send_prev, int64_t n_send_prev,
+                                              double* recv_prev, int64_t n_recv_prev,
+                                              const double* send_next, int64_t n_send_next,
+                                              double* recv_next, int64_t n_recv_next, void* stream);
+/* out = [the `count` doubles of rank 0 | of rank 1 | ...]; in == out + rank * count is allowed */
+amg_hip_status amg_hip_comm_all_gather(amg_hip_comm* c, const double* in, double* out, int64_t count,
+                                       void* stream);
+/* One slab-sharded V-cycle (the slab section above): `info` is what amg_hip_slab_setup returned
+ * for (amg_hip_comm_rank, amg_hip_comm_world).  With a communicator of one rank this is
+ * amg_hip_vcycle cut into its three graphs: same bits.                                       */
+amg_hip_status amg_hip_slab_cycle(amg_hip_solver* s, amg_hip_comm* c, const amg_hip_slab_info* info);
+/* One window-sharded V-cycle (the window section above): `w` the window solver, `t` the solver of
+ * the replicated levels >= k (built from the gathered rows of A_k), both on ONE stream.  All
+ * offsets / counts in doubles:
+ *   level-0 solution of the window: owned rows [own0_off, own0_end); send_prev_cnt of its first
+ *   rows go to rank-1, send_next_cnt of its last rows to rank+1; recv_prev_cnt rows arrive below
+ *   own0_off, recv_next_cnt rows from own0_end on;
+ *   level k: owned rows [own_k_off, own_k_off + own_k_cnt) of the window's f_k are this rank's
+ *   block (block_k doubles per rank, padded) of the all-gather; the window's u_k is rows
+ *   [uk_off, uk_off + n) of the tail's solution.                                            */
+typedef struct amg_hip_window_plan {
+  int64_t own0_off, own0_end;
+  int64_t send_prev_cnt, recv_prev_cnt, send_next_cnt, recv_next_cnt;
+  int64_t own_k_off, own_k_cnt, block_k, uk_off;
+} amg_hip_window_plan;
+amg_hip_status amg_hip_window_cycle(amg_hip_solver* w, amg_hip_solver* t, amg_hip_comm* c,
+                                    const amg_hip_window_plan* p);
 
 /* Multigrid::solve(), multigrid.hpp:311-337: while (iter < n_iters && error >
  * tol) { vcycle(); if (++iter % every == 0) error = rss }.  error starts at 100.
