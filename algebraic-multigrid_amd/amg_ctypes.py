@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libamg_hip.so")
 
-OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED = 0, 1, 2, 3, 4
+OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED, ECOMM = 0, 1, 2, 3, 4, 5
 SM_SPGS, SM_REF_JACOBI, SM_SOR, SM_JACOBI, SM_MULTICOLOR_GS = 0, 1, 2, 3, 4
 LAYOUT_AUTO, LAYOUT_CSR, LAYOUT_SELL, LAYOUT_DICT = 0, 1, 2, 3
 

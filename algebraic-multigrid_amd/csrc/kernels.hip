@@ -990,14 +990,16 @@ __device__ __forceinline__ void patch_eval_u(const double* buf, int cell0, const
                                              const double (&f)[PATCH_K], double omega,
                                              double (&res)[PATCH_K]) {
   const double* p = buf + cell0 - PATCH_EC;  // line above the first cell
-  if (!RESID && U.diag == 0.0) {  // rows without a diagonal keep their value (smoother.hpp:133)
+  if (!CORNERS && !RESID && U.diag == 0.0) {  // rows without a diagonal keep their value (smoother.hpp:133)
 #pragma unroll
     for (int k = 0; k < PATCH_K; ++k) res[k] = p[(k + 1) * PATCH_EC];
     return;
   }
-  // (the test above is wave-uniform and sits OUTSIDE the cell loop: inside it, it cut the loop
-  // into one basic block per cell and the eight independent dependency chains -- LDS read, sums,
-  // IEEE division -- ran one after the other instead of interleaved)
+  // (5-point rows: the test above is wave-uniform and sits OUTSIDE the cell loop; inside it, it
+  // cuts the loop into one basic block per cell and the eight independent dependency chains --
+  // LDS read, sums, IEEE division -- run one after the other instead of interleaved.  For the
+  // 9-point rows that is what the 72-register budget of four workgroups per CU wants: there the
+  // test stays inside the loop, measured 10 % faster on levels 1-3.)
   double w[3][3];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
@@ -1037,7 +1039,9 @@ __device__ __forceinline__ void patch_eval_u(const double* buf, int cell0, const
         if (MASK >= 0 && !((MASK >> s9) & 1)) continue;
         acc += U.wj[s9] * w[r][c];
       }
-      {
+      if (CORNERS && U.diag == 0.0) {
+        res[k] = xi;
+      } else {
 #ifdef AMG_PATCH_FASTDIV
         // experiment: Markstein's correctly rounded quotient from the (wave-uniform) reciprocal
         const double nm = f[k] - acc;
@@ -1057,9 +1061,6 @@ __device__ __forceinline__ void patch_eval_u(const double* buf, int cell0, const
       w[0][c] = w[1][c];
       w[1][c] = w[2][c];
     }
-    // 9-point rows: keep the cells apart (interleaving them costs more registers than the 72 that
-    // four workgroups per CU leave: measured slower on levels 1-3); 5-point rows interleave
-    if (CORNERS) __builtin_amdgcn_sched_barrier(0);
   }
 }
 // Row arithmetic of dict_rows, per-lane table entries from the LDS copy (mixed row types:
@@ -1133,7 +1134,7 @@ __device__ __forceinline__ void patch_stage(const PatchCells& pc, int m, int nty
     // for the whole wave, weights in scalar registers; cells outside the region are evaluated
     // with it too (their reads stay inside the guard lines) and dropped.  Every other wave
     // (level boundaries) takes the per-lane table.
-    patch_eval_u<RESID, (UM & 0x145) != 0, false, UM>(buf, pc.cell0, U, pc.f, omega, res);
+    patch_eval_u<RESID, (UM & 0x145) != 0, false, (UM & 0x145) ? -1 : UM>(buf, pc.cell0, U, pc.f, omega, res);
   } else {
 #pragma unroll
     for (int k = 0; k < PATCH_K; ++k)
@@ -1403,7 +1404,7 @@ __device__ __forceinline__ void patch_stage_color(const PatchCells& pc, int ntyp
     did[k] = inc && lj >= l0 && lj < l1 && pc.live[k] && ((parbits >> k) & 1u) == cpar;
   }
   if (pc.uniform && U.rmask == (uint32_t)UM) {
-    patch_eval_u<false, (UM & 0x145) != 0, true, UM>(buf, pc.cell0, U, pc.f, 1.0, res);
+    patch_eval_u<false, (UM & 0x145) != 0, true, (UM & 0x145) ? -1 : UM>(buf, pc.cell0, U, pc.f, 1.0, res);
   } else {
 #pragma unroll
     for (int k = 0; k < PATCH_K; ++k)

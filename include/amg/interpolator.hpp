@@ -33,7 +33,7 @@ class InterpolatorBase {
 
  public:
   InterpolatorBase() = default;
-  explicit InterpolatorBase(size_t n_levels) : prolong_(n_levels - 1), restrict_(n_levels - 1) {}
+  InterpolatorBase(size_t n_levels) : prolong_(n_levels - 1), restrict_(n_levels - 1) {}
   virtual ~InterpolatorBase() = default;
 
   // fills P and R of `level` for a fine level of n_h_dofs and a coarse one of n_H_dofs
