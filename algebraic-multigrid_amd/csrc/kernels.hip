@@ -1270,6 +1270,36 @@ hipError_t launch_patch_tile_flags(int64_t n, int64_t m, const uint8_t* rtype, i
   return hipGetLastError();
 }
 
+// cflag[tile] = 1 when every coarse row the down-leg of the tile produces (c = i / 2 for the even
+// fine rows i of the patch) has the diagonal dref, bit for bit.
+__global__ __launch_bounds__(256) void patch_coarse_flags_kernel(int n, int m, int px_count, int nH,
+                                                                 const double* __restrict__ diagH, double dref,
+                                                                 uint8_t* __restrict__ cflag) {
+  const int tile = blockIdx.x;
+  const int py = tile / px_count, px = tile - py * px_count;
+  const int j0 = py * PATCH_TH, i0 = px * PATCH_TW;
+  int ok = 1;
+  for (int q = threadIdx.x; q < PATCH_TH * (PATCH_TW / 2); q += 256) {
+    const int lj = q / (PATCH_TW / 2), cx = q - lj * (PATCH_TW / 2);
+    const int64_t i = (int64_t)(j0 + lj) * m + i0 + 2 * cx;
+    const int64_t c = i >> 1;
+    if (i >= (int64_t)n || c >= nH) continue;
+    ok = ok && __double_as_longlong(diagH[c]) == __double_as_longlong(dref);
+  }
+  ok = __syncthreads_and(ok);
+  if (threadIdx.x == 0) cflag[tile] = ok ? 1 : 0;
+}
+hipError_t launch_patch_coarse_flags(int64_t n, int64_t m, int64_t nH, const double* diagH, double dref,
+                                     uint8_t* cflag, hipStream_t st) {
+  if (!patch_geometry_ok(n, m) || !diagH || !cflag) return hipErrorInvalidValue;
+  const int64_t lines = (n + m - 1) / m;
+  const int pxc = (int)(m / PATCH_TW);
+  const int64_t tiles = (lines + PATCH_TH - 1) / PATCH_TH * pxc;
+  hipLaunchKernelGGL(patch_coarse_flags_kernel, dim3((unsigned)tiles), dim3(256), 0, st, (int)n, (int)m, pxc,
+                     (int)nH, diagH, dref, cflag);
+  return hipGetLastError();
+}
+
 __device__ __forceinline__ void patch_stage_tables(PatchJ* tabJ, PatchR* tabR,
                                                    const double* __restrict__ ptab, int nent) {
   // ptab: nent x {aJ, d, aR, loff (as double; -1e9 = unused slot)}; slots past nent: absent
@@ -1306,13 +1336,18 @@ __device__ __forceinline__ void patch_prologue(const PatchCells& pc, double* buf
 
 // FIRST: the input is the level's u and both pre-sweeps run here (level 0); else the input
 // is the result of the first sweep (done by the finer level's kernel) and one sweep runs.
+// (Tried and dropped: at most 1024 workgroups per launch, each walking several patches of its XCD's
+// run with the tables staged once -- the loop alone cost 20 % (165 vs 134 us on level 0), with
+// 1024 workgroups 204 us: the slots of a CU standing empty 40 % of the time
+// (SQ_WAVE_CYCLES / (slots x duration) = 0.59) is not workgroup turnover.)
 template <int UN, int UM, bool FIRST, bool NT>
 __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
     int nent, int ntypes, const double* x, const double* __restrict__ f, double* u_out, double* r_out, int nH,
     double* __restrict__ fH, const double* __restrict__ diagH, double* __restrict__ uH1,
-    double omega, int xcd_map, int py0, const uint8_t* __restrict__ tflag) {
+    double omega, int xcd_map, int py0, const uint8_t* __restrict__ tflag,
+    const uint8_t* __restrict__ cflag, double dHu) {
   __shared__ double buf[PATCH_BUF];
   __shared__ PatchJ tabJ[PATCH_MAXTAB];
   __shared__ PatchR tabR[PATCH_MAXTAB];
@@ -1322,22 +1357,26 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
   PatchCells pc;
   PatchU U;
   const uint32_t tf = tflag ? (uint32_t)tflag[(py + py0) * px_count + px] : 255u;
+  // every coarse row under this patch has the diagonal dHu (launch_patch_coarse_flags found that
+  // out at setup): the first coarse sweep then needs no load of the coarse diagonal at the very
+  // end of the workgroup's life, where nothing is left to hide its latency behind
+  const bool cuni = cflag && cflag[(py + py0) * px_count + px] != 0;
   if (tf != 255u) patch_load<false, true>(pc, tf, n, m, j0, i0, x, f, rtype, ntypes, nullptr, 0, buf);
   else patch_load<false, false>(pc, tf, n, m, j0, i0, x, f, rtype, ntypes, nullptr, 0, buf);
   patch_prologue(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U);
   lds_barrier();
   if (FIRST) {
     patch_stage<UN, UM, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -2, PATCH_TH + 2, -2,
-                                      PATCH_TW + 3, nullptr);
+                                          PATCH_TW + 3, nullptr);
     lds_barrier();
   }
   patch_stage<UN, UM, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
-                                    PATCH_TW + 2, nullptr);
+                                        PATCH_TW + 2, nullptr);
   lds_barrier();
   patch_copy_out<NT>(buf, u_out, n, m, j0, i0);  // the residual stage below only reads until its barrier
   // residual; rows outside the matrix read as 0.0 for the restriction (ZERO)
   patch_stage<UN, UM, true, NT, true>(pc, m, ntypes, buf, U, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW + 1,
-                                  r_out);
+                                      r_out);
   lds_barrier();
   const double* rsb = buf;
   // restriction + first coarse sweep: coarse row c <-> even fine row 2c of the patch
@@ -1353,7 +1392,7 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
     if (i + 2 < n) sum += 0.5 * rs[2];
     fH[c] = sum;
     const double xi = 0.0, acc = 0.0;  // jacobi_from_zero_kernel
-    const double d = diagH[c];
+    const double d = cuni ? dHu : diagH[c];
     uH1[c] = (d == 0.0) ? xi : xi + omega * ((sum - acc) / d - xi);
   }
 }
@@ -1378,10 +1417,10 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_up_kernel(
   patch_prologue(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U);
   lds_barrier();
   patch_stage<UN, UM, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
-                                    PATCH_TW + 1, nullptr);
+                                        PATCH_TW + 1, nullptr);
   lds_barrier();
   patch_stage<UN, UM, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW,
-                                    nullptr);
+                                        nullptr);
   lds_barrier();
   patch_copy_out<NT>(buf, u_out, n, m, j0, i0);
 }
@@ -1530,11 +1569,11 @@ hipError_t launch_patch_down(bool first, int64_t n, int64_t m, const PatchRef& P
     if (first)
       hipLaunchKernelGGL((patch_down_kernel<decltype(U)::value, decltype(M)::value, true, decltype(NTF)::value>), dim3(grid),
                          dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, u_out,
-                         r_out, (int)nH, fH, diagH, uH1, omega, xm, py0, P.tflag);
+                         r_out, (int)nH, fH, diagH, uH1, omega, xm, py0, P.tflag, P.cflag, P.dHu);
     else
       hipLaunchKernelGGL((patch_down_kernel<decltype(U)::value, decltype(M)::value, false, decltype(NTF)::value>), dim3(grid),
                          dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi, P.nent, P.ntypes, x, f, u_out,
-                         r_out, (int)nH, fH, diagH, uH1, omega, xm, py0, P.tflag);
+                         r_out, (int)nH, fH, diagH, uH1, omega, xm, py0, P.tflag, P.cflag, P.dHu);
   });
 }
 hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double* x, const double* f,

@@ -100,7 +100,12 @@ struct PatchRef {
   const uint8_t* tflag = nullptr;
   int nent = 0, ntypes = 0, un = 0, nt = 0;
   int umask = 0;  // slots (3 x 3, bit = slot) of the level's interior row type: selects the kernel kind
+  // down-leg: per tile 1 when every coarse row under it has the diagonal dHu (launch_patch_coarse_flags)
+  const uint8_t* cflag = nullptr;
+  double dHu = 0.0;
 };
+hipError_t launch_patch_coarse_flags(int64_t n, int64_t m, int64_t nH, const double* diagH, double dref,
+                                     uint8_t* cflag, hipStream_t st);
 // flag == null: only *n_tiles is computed (the size of the array)
 hipError_t launch_patch_tile_flags(int64_t n, int64_t m, const uint8_t* rtype, int ntypes, uint8_t* flag,
                                    int64_t* n_tiles, hipStream_t st);

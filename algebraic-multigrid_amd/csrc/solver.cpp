@@ -261,10 +261,15 @@ struct DevMat {
   int64_t patch_m = 0;
   int patch_un = 0, patch_ntypes = 0, patch_umask = 0;
   DevMem patch_tab, patch_utabd, patch_utabi, patch_flags;
+  DevMem patch_cflags;      // per tile: the coarse rows under it share the diagonal patch_dH (set_patch_coarse_flags)
+  double patch_dH = 0.0;
+  double patch_cfrac = 0.0;  // fraction of the tiles whose flag is set (bytes accounting)
   PatchRef patch_ref() const {
     PatchRef P;
     P.rtype = drtype.as<uint8_t>();
     P.tflag = g_patch_tile_flags ? patch_flags.as<uint8_t>() : nullptr;
+    P.cflag = g_patch_tile_flags ? patch_cflags.as<uint8_t>() : nullptr;
+    P.dHu = patch_dH;
     P.ptab = patch_tab.as<double>();
     P.utabd = patch_utabd.as<double>();
     P.utabi = patch_utabi.as<int32_t>();
@@ -616,7 +621,17 @@ constexpr int64_t GS_SCAN_MIN_GAP = 4;
 constexpr int64_t COARSE_SPIKE_MIN_ROWS = 4096;
 // multicolour GS: levels of at most this many rows run a whole symmetric pass as ONE launch
 // (one workgroup, barriers between the colours) instead of one launch per colour and direction
-constexpr int64_t MC_ONE_LAUNCH_MAX_ROWS = 8192;
+// Multicolour levels of at most this many rows run the whole symmetric pass in ONE launch (one
+// workgroup, a barrier between colours) instead of one launch per colour and direction; larger
+// levels lose more to the single CU than the launches cost.  AMG_HIP_MC_ONE_LAUNCH_ROWS overrides
+// (tuning / A-B; same bits).
+int64_t mc_one_launch_max_rows() {
+  static const int64_t v = [] {
+    const char* e = std::getenv("AMG_HIP_MC_ONE_LAUNCH_ROWS");
+    return e ? std::atoll(e) : (int64_t)8192;
+  }();
+  return v;
+}
 // want_fast: 1 = partitioned whenever it applies, 0 = by size, -1 = never
 amg_hip_status upload_coarse(const Sparse& A, int want_fast, CoarseOnDev* C) {
   BandFactor F;
@@ -1119,7 +1134,8 @@ amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
           const double lines = (double)((L.n + A.patch_m - 1) / A.patch_m);
           frac = std::min(1.0, (double)(sb.down_hi[l] - sb.down_lo[l]) / lines);
         }
-        s->acct(frac * (25.0 * L.n + 24.0 * C.n + (s->opt.keep_residual ? 8.0 * L.n : 0.0)));
+        // (the coarse diagonal is not read under the tiles that take it as an argument)
+        s->acct(frac * (25.0 * L.n + (24.0 - 8.0 * A.patch_cfrac) * C.n + (s->opt.keep_residual ? 8.0 * L.n : 0.0)));
       }
       first_sweep_done = true;
       continue;
@@ -1283,6 +1299,36 @@ amg_hip_status set_device(const amg_hip_solver* s) {
   if (s->opt.host_only)
     return fail(AMG_HIP_EINVAL, "solver was created with host_only = 1: no device state");
   HIP_TRY(hipSetDevice(s->device));
+  return AMG_HIP_OK;
+}
+
+// K-Patch down-legs: which tiles sit over coarse rows that all share one diagonal value (the
+// interior of the coarse level) -- those workgroups take it as a kernel argument instead of loading
+// it per coarse row at the end of their life.  Called once the whole hierarchy is on the device.
+amg_hip_status set_patch_coarse_flags(amg_hip_solver* s) {
+  for (size_t l = 0; l + 1 < s->lv.size(); ++l) {
+    Level& L = s->lv[l];
+    Level& C = s->lv[l + 1];
+    DevMat& A = L.A_rows;
+    if (!A.patch || !C.diag.p || C.n < 1) continue;
+    int64_t tiles = 0;
+    HIP_TRY(launch_patch_tile_flags(L.n, A.patch_m, nullptr, A.patch_ntypes, nullptr, &tiles, nullptr));
+    // reference value: the coarse row under the middle of the middle line (C.n / 2 would be a line end)
+    const int64_t lines = (L.n + A.patch_m - 1) / A.patch_m;
+    const int64_t cref = std::min<int64_t>(C.n - 1, ((lines / 2) * A.patch_m + A.patch_m / 2) >> 1);
+    double dref = 0.0;
+    HIP_TRY(hipMemcpy(&dref, C.diag.as<double>() + cref, sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(A.patch_cflags.alloc((size_t)tiles));
+    HIP_TRY(launch_patch_coarse_flags(L.n, A.patch_m, C.n, C.diag.as<double>(), dref,
+                                      A.patch_cflags.as<uint8_t>(), nullptr));
+    A.patch_dH = dref;
+    std::vector<uint8_t> fl((size_t)tiles);
+    HIP_TRY(hipMemcpy(fl.data(), A.patch_cflags.p, fl.size(), hipMemcpyDeviceToHost));
+    int64_t on = 0;
+    for (uint8_t f : fl) on += f != 0;
+    A.patch_cfrac = g_patch_tile_flags && tiles > 0 ? (double)on / (double)tiles : 0.0;
+  }
+  HIP_TRY(hipDeviceSynchronize());
   return AMG_HIP_OK;
 }
 
@@ -1507,7 +1553,7 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
       }
       HIP_TRY(upload(L.mc_rowid, CP.rowid.data(), CP.rowid.size()));
       L.mc_start = CP.start;
-      if (L.mc_dict && L.n <= MC_ONE_LAUNCH_MAX_ROWS) {
+      if (L.mc_dict && L.n <= mc_one_launch_max_rows()) {
         std::vector<int32_t> st32(CP.start.begin(), CP.start.end());
         HIP_TRY(upload(L.mc_start_dev, st32.data(), st32.size()));
       }
@@ -1618,6 +1664,10 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
   }
   timer.lap(T_BAND);
   HIP_TRY(s->scratch.alloc(sizeof(double) * 1100));
+  {
+    amg_hip_status r = set_patch_coarse_flags(s.get());
+    if (r != AMG_HIP_OK) return r;
+  }
   compute_bytes(s.get());
   HIP_TRY(hipDeviceSynchronize());
   *out = s.release();
@@ -1956,6 +2006,10 @@ amg_hip_status build_poisson_device(int dim, int64_t n, int32_t n_levels, const 
   }
   lap("coarse factor");
   HIP_TRY(s->scratch.alloc(sizeof(double) * 1100));
+  {
+    amg_hip_status r = set_patch_coarse_flags(s.get());
+    if (r != AMG_HIP_OK) return r;
+  }
   compute_bytes(s.get());
   HIP_TRY(hipDeviceSynchronize());
   *unsupported = false;
@@ -2807,7 +2861,7 @@ amg_hip_status amg_hip_fine_sweep_info(const amg_hip_solver* s, char* name, int3
     std::snprintf(name, (size_t)name_cap, "patch_down_kernel<%d, %d, true, %s>", patch_un(A.patch_un),
                   patch_kind_umask(A.patch_un, A.patch_umask), A.dict_nt ? "true" : "false");
     sweeps = 2;
-    bytes = 25.0 * (double)L.n + 24.0 * (double)s->lv[1].n;
+    bytes = 25.0 * (double)L.n + (24.0 - 8.0 * A.patch_cfrac) * (double)s->lv[1].n;
     if (s->slab.levels > 0 && s->slab.world > 1) {  // the tiles this rank's launch covers
       const int64_t th = patch_tile_lines();
       const int64_t l0 = s->slab.down_lo[0] / th * th;
