@@ -1340,6 +1340,30 @@ __device__ __forceinline__ void patch_prologue(const PatchCells& pc, double* buf
 // run with the tables staged once -- the loop alone cost 20 % (165 vs 134 us on level 0), with
 // 1024 workgroups 204 us: the slots of a CU standing empty 40 % of the time
 // (SQ_WAVE_CYCLES / (slots x duration) = 0.59) is not workgroup turnover.)
+#ifdef AMG_PATCH_STAMPS
+// DIAGNOSTIC BUILD ONLY (never shipped, never timed): per workgroup the 100 MHz wall clock at the
+// phase boundaries of the down-leg and the hardware id of the CU it ran on, into a buffer of its
+// own (tools/patch_stamps.py reads it: phase shares, workgroups resident per CU, dispatch gaps).
+__device__ unsigned long long* g_patch_stamps = nullptr;
+__device__ __forceinline__ void patch_stamp(int k) {
+  if (threadIdx.x == 0 && g_patch_stamps) {
+    unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    g_patch_stamps[(size_t)blockIdx.x * 8 + k] = t;
+    if (k == 0) {
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID
+      g_patch_stamps[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+  }
+}
+hipError_t debug_set_patch_stamps(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_patch_stamps), &p, sizeof(p));
+}
+#define PATCH_STAMP(k) patch_stamp(k)
+#else
+#define PATCH_STAMP(k)
+#endif
 template <int UN, int UM, bool FIRST, bool NT>
 __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
@@ -1351,6 +1375,7 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
   __shared__ double buf[PATCH_BUF];
   __shared__ PatchJ tabJ[PATCH_MAXTAB];
   __shared__ PatchR tabR[PATCH_MAXTAB];
+  PATCH_STAMP(0);
   const int tile = xcd_tile(blockIdx.x, gridDim.x, xcd_map);
   const int py = tile / px_count, px = tile - py * px_count;
   const int j0 = (py + py0) * PATCH_TH, i0 = px * PATCH_TW;
@@ -1365,19 +1390,23 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
   else patch_load<false, false>(pc, tf, n, m, j0, i0, x, f, rtype, ntypes, nullptr, 0, buf);
   patch_prologue(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U);
   lds_barrier();
+  PATCH_STAMP(1);
   if (FIRST) {
     patch_stage<UN, UM, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -2, PATCH_TH + 2, -2,
                                           PATCH_TW + 3, nullptr);
     lds_barrier();
   }
+  PATCH_STAMP(2);
   patch_stage<UN, UM, false, NT, false>(pc, m, ntypes, buf, U, tabJ, tabR, omega, -1, PATCH_TH + 1, -1,
                                         PATCH_TW + 2, nullptr);
   lds_barrier();
+  PATCH_STAMP(3);
   patch_copy_out<NT>(buf, u_out, n, m, j0, i0);  // the residual stage below only reads until its barrier
   // residual; rows outside the matrix read as 0.0 for the restriction (ZERO)
   patch_stage<UN, UM, true, NT, true>(pc, m, ntypes, buf, U, tabJ, tabR, omega, 0, PATCH_TH, 0, PATCH_TW + 1,
                                       r_out);
   lds_barrier();
+  PATCH_STAMP(4);
   const double* rsb = buf;
   // restriction + first coarse sweep: coarse row c <-> even fine row 2c of the patch
   for (int q = threadIdx.x; q < PATCH_TH * (PATCH_TW / 2); q += PATCH_NT) {
@@ -1395,6 +1424,7 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
     const double d = cuni ? dHu : diagH[c];
     uH1[c] = (d == 0.0) ? xi : xi + omega * ((sum - acc) / d - xi);
   }
+  PATCH_STAMP(5);
 }
 
 template <int UN, int UM, bool NT>

@@ -23,6 +23,9 @@
 #include "kernels.hpp"
 
 using namespace amg_hip;
+#ifdef AMG_PATCH_STAMPS
+namespace amg_hip { hipError_t debug_set_patch_stamps(unsigned long long* p); }
+#endif
 
 namespace {
 
@@ -2387,6 +2390,13 @@ amg_hip_status amg_hip_window_run(amg_hip_solver* s, int32_t part) {
   }
   return amg_hip_slab_run(s, part);
 }
+
+#ifdef AMG_PATCH_STAMPS
+amg_hip_status amg_hip_debug_patch_stamps(void* dev_ptr) {  // diagnostic build only (tools/patch_stamps.py)
+  HIP_TRY(debug_set_patch_stamps((unsigned long long*)dev_ptr));
+  return AMG_HIP_OK;
+}
+#endif
 
 amg_hip_status amg_hip_get_stream(amg_hip_solver* s, void** stream) {
   if (!s || !stream) return fail(AMG_HIP_EINVAL, "bad argument");
