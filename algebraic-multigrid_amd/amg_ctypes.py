@@ -329,6 +329,9 @@ def set_band_chain(on):
     lib().amg_hip_set_band_chain(int(bool(on)))
 
 
+PATCH_MIN_ROWS_DEFAULT = 1000000   # the library's default K-Patch threshold (amg_hip_set_patch_min_rows)
+
+
 def set_patch_min_rows(rows):
     lib().amg_hip_set_patch_min_rows(int(rows))
 

@@ -817,7 +817,7 @@ struct Slab {
   }
 };
 
-int64_t g_patch_min_rows = (int64_t)1 << 20;  // amg_hip_set_patch_min_rows
+int64_t g_patch_min_rows = 1000000;  // amg_hip_set_patch_min_rows (level 4 of 4096^2 has 1 048 575 rows)
 
 struct amg_hip_solver {
   amg_hip_options opt;

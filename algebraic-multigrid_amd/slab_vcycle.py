@@ -180,7 +180,7 @@ class HipSlabEngine:
                                             omega=omega, device=device.index, stream=stream.cuda_stream)
         finally:
             if patch_min_rows is not None:
-                amg.set_patch_min_rows(1 << 20)
+                amg.set_patch_min_rows(amg.PATCH_MIN_ROWS_DEFAULT)
         try:
             self.info = self.mg.slab_setup(rank, world, max_levels)
         except Exception:

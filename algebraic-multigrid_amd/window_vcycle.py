@@ -430,7 +430,7 @@ class HipWindowEngine:
                                                    use_graph=use_graph)
         finally:
             if patch_min_rows is not None:
-                amg.set_patch_min_rows(1 << 20)
+                amg.set_patch_min_rows(amg.PATCH_MIN_ROWS_DEFAULT)
         for l in range(plan.k + 1):
             if self.mg.get_n_dofs(l) != plan.window_rows(l):
                 raise RuntimeError("window hierarchy does not have the planned level sizes")

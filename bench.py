@@ -309,7 +309,7 @@ def main():
     ap.add_argument("--dict-rows", type=int, default=2, choices=[1, 2], help="K-Dict rows per lane")
     ap.add_argument("--patch-min-rows", type=int, default=None,
                     help="K-Patch (temporal blocking) on levels of at least this many rows "
-                         "(default 2^20; -1 = off)")
+                         "(default 10^6; -1 = off)")
     ap.add_argument("--fast-coarse", action="store_true",
                     help="partitioned (parallel) coarse solve; then fewer levels pay off (--levels 13)")
     ap.add_argument("--host-setup", action="store_true",

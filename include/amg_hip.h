@@ -165,7 +165,7 @@ void amg_hip_set_row_types(int32_t on);
 void amg_hip_set_dict_rows(int32_t rows_per_lane);
 /* K-Patch (temporal blocking of the 2+2 true-Jacobi cycle: a level's down-leg and up-leg in
  * one launch each over 2-D patches of the level) is used on levels of at least this many rows
- * (default 2^20; negative = never).  Process-wide, read when a solver is created: existing
+ * (default 10^6; negative = never).  Process-wide, read when a solver is created: existing
  * solvers keep theirs.  Bit-identical results; tests set 0.                              */
 void amg_hip_set_patch_min_rows(int64_t rows);
 

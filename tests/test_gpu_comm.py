@@ -35,7 +35,7 @@ def test_slab_cycle_through_the_library_communicator(amg, comm1):
         ref = amg.Multigrid.poisson(n, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
         mg = amg.Multigrid.poisson(n, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
     finally:
-        amg.set_patch_min_rows(1 << 20)
+        amg.set_patch_min_rows(amg.PATCH_MIN_ROWS_DEFAULT)
     info = mg.slab_setup(0, 1)
     assert info.levels >= 3
     for c in range(3):

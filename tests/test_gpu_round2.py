@@ -235,7 +235,7 @@ def test_config5_512cubed_full_size(amg):
 def patch_everywhere(amg):
     amg.set_patch_min_rows(0)          # every level whose band has a 2-D pitch >= 128
     yield
-    amg.set_patch_min_rows(1 << 20)
+    amg.set_patch_min_rows(amg.PATCH_MIN_ROWS_DEFAULT)
 
 
 @pytest.mark.parametrize("n,L,keep", [(128, 4, False), (256, 6, True), (512, 7, False), (192, 5, True)])
@@ -280,7 +280,7 @@ def test_patch_on_off_identical_1024(amg):
         mg.vcycle(3)
         out.append((mg.get_soln(0), mg.get_soln(1), mg.get_rhs(2), mg.rss()))
         mg.close()
-    amg.set_patch_min_rows(1 << 20)
+    amg.set_patch_min_rows(amg.PATCH_MIN_ROWS_DEFAULT)
     for a, c in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(a, c)
     assert out[0][3] == out[1][3]
@@ -617,7 +617,7 @@ def test_patch_tile_flags_on_off_identical(amg):
         out.append((mg.get_soln(0), mg.get_soln(2), mg.get_rhs(3), mg.rss()))
         mg.close()
     amg.set_patch_tile_flags(True)
-    amg.set_patch_min_rows(1 << 20)
+    amg.set_patch_min_rows(amg.PATCH_MIN_ROWS_DEFAULT)
     for a, c in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(a, c)
     assert out[0][3] == out[1][3]
@@ -636,7 +636,7 @@ def test_multicolor_patch_form_bit_exact(amg, oracle):
         mg = amg.Multigrid(A.colptr, A.rowind, A.val, b, L, smoother=amg.SM_MULTICOLOR_GS, smoother_iters=1,
                            exact_coarse_solve=True, keep_residual=True)
     finally:
-        amg.set_patch_min_rows(1 << 20)
+        amg.set_patch_min_rows(amg.PATCH_MIN_ROWS_DEFAULT)
     assert mg.fine_sweep_info()[0].startswith("patch_rb_kernel")
     ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_MULTICOLOR, smoother_iters=1)
     for l in range(L):

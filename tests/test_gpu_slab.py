@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def patch_everywhere(amg):
     amg.set_patch_min_rows(0)      # K-Patch on every level whose geometry allows it
     yield
-    amg.set_patch_min_rows(1 << 20)
+    amg.set_patch_min_rows(amg.PATCH_MIN_ROWS_DEFAULT)
 
 
 def _engines(amg, n, L, world, max_levels):
@@ -110,7 +110,7 @@ def test_slab_full_size_4096_eight_ranks(amg, pmr, k):
     try:
         engs, st = _engines(amg, n, L, world, -1)
     finally:
-        amg.set_patch_min_rows(1 << 20)
+        amg.set_patch_min_rows(amg.PATCH_MIN_ROWS_DEFAULT)
     assert int(engs[0].info.levels) == k and int(engs[0].info.halo_lines) == 6 * k - 1
     for c in range(3):
         ref.vcycle()

@@ -30,7 +30,7 @@ JAC, MC = 3, 4
 def patch_everywhere(amg):
     amg.set_patch_min_rows(0)      # K-Patch on every level whose geometry allows it
     yield
-    amg.set_patch_min_rows(1 << 20)
+    amg.set_patch_min_rows(amg.PATCH_MIN_ROWS_DEFAULT)
 
 
 def _sharded(amg, dim, n, L, k, world, smoother, iters, omega, cycles):

@@ -75,8 +75,8 @@ def must_move(kind, l):
         return n * 17 + nH * 24
     if kind == "jacobi_prolong":             # + read-modify-write of the finer u
         return n * 25 + LEVEL_ROWS[l - 1] * 16
-    if kind in ("patch_down_first", "patch_down"):   # x, f, type, smoothed u; f_H, u_H, coarse diagonal
-        return n * 25 + nH * 24
+    if kind in ("patch_down_first", "patch_down"):   # x, f, type, smoothed u; f_H, u_H (the coarse diagonal is a
+        return n * 25 + nH * 16                      # kernel argument under interior tiles: > 99 % of them)
     if kind == "patch_up":                   # x, f, type, u_H in; u out
         return n * 25 + nH * 8
     if kind == "sell":
@@ -111,8 +111,9 @@ def main():
                                "traffic_bytes": tr, "must_move_bytes": mm, "csr_formula_bytes": alg}
     lines += ["", "`must move` = what one launch has to read and write once (bench.py roofline.algorithmic_bytes_per_launch):",
               "dict_kernel: 1 B row type + f + x + out per row; the fused forms add their transfer operands;",
-              "patch_down_kernel<slots, first, nt>: the level's whole down-leg (x, f, type in; smoothed u, f_H, first coarse",
-              "sweep out; coarse diagonal in), patch_up_kernel: the up-leg (x, f, type, u_H in; u out).  traffic / must move",
+              "patch_down_kernel<slots, mask, first, nt>: the level's whole down-leg (x, f, type in; smoothed u, f_H, first coarse",
+              "sweep out; the coarse diagonal is a kernel argument under interior tiles), patch_up_kernel: the up-leg (x, f, type,",
+              "u_H in; u out).  traffic / must move",
               "above 1 = halo re-reads that miss the L2 / Infinity Cache.", ""]
     out_dir = os.environ.get("PMC_OUT_DIR", os.path.join(ROOT, "profiles"))
     os.makedirs(out_dir, exist_ok=True)
