@@ -18,6 +18,8 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "../../include/amg_hip.h"
 #include "host_setup.hpp"
 #include "kernels.hpp"
@@ -1075,6 +1077,43 @@ amg_hip_status enqueue_residual(amg_hip_solver* s, int l) {
 // over this rank's lines, the replicated rest below them (it begins by redoing the from-zero
 // sweep of its first level on the gathered right-hand side), the up-legs of the slab levels.
 enum { CYCLE_ALL = 0, CYCLE_SLAB_DOWN = 1, CYCLE_SLAB_TAIL = 2, CYCLE_SLAB_UP = 3 };
+// roctx ranges per level and leg, AMG_HIP_ROCTX=1: "L<l> down" / "L<l> up" /
+// "coarse solve" around what is ENQUEUED for them (librocprofiler-sdk-roctx by dlopen; the ranges
+// bracket the launches, so they line up with the kernels in a `rocprofv3 --marker-trace
+// --kernel-trace` run of an eager cycle, use_graph = 0 / bench.py --no-graph; under a captured
+// graph they mark the capture only).
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    if (!std::getenv("AMG_HIP_ROCTX")) return;
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) push = nullptr;
+  }
+};
+struct RoctxRange {
+  static Roctx& api() {
+    static Roctx r;
+    return r;
+  }
+  bool on = false;
+  RoctxRange(const char* what, int level) {
+    if (!api().push) return;
+    char name[48];
+    if (level >= 0) std::snprintf(name, sizeof(name), "L%d %s", level, what);
+    else std::snprintf(name, sizeof(name), "%s", what);
+    api().push(name);
+    on = true;
+  }
+  ~RoctxRange() {
+    if (on) api().pop();
+  }
+};
+
 amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part);
 amg_hip_status enqueue_vcycle(amg_hip_solver* s, int part = CYCLE_ALL) {
   s->must_move[part] = 0;
@@ -1101,6 +1140,7 @@ amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
   const int down_from = part == CYCLE_SLAB_TAIL ? k : 0;
   const int down_to = part == CYCLE_SLAB_DOWN ? k : (part == CYCLE_SLAB_UP ? 0 : nl);
   for (int l = down_from; l < down_to; ++l) {
+    RoctxRange range("down", l);
     // On the coarsest level the reference smooths and forms the residual, then overwrites
     // u with the direct solve of the level's rhs (multigrid.hpp:268-274, :287-288): unless
     // the residual is to be kept, neither has an observable effect.
@@ -1197,6 +1237,7 @@ amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
     }
   }
   if (!ranged) {                                                   // :287-288
+    RoctxRange range("coarse solve", -1);
     if (s->opt.window)
       return fail(AMG_HIP_EINVAL, "a window solver (opt.window) runs by parts: amg_hip_window_run");
     Level& C = s->lv[nl - 1];
@@ -1213,6 +1254,7 @@ amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
   const int up_from = part == CYCLE_SLAB_UP ? k - 1 : (part == CYCLE_SLAB_DOWN ? -1 : nl - 2);
   const int up_to = part == CYCLE_SLAB_TAIL ? k : 0;
   for (int l = up_from; l >= up_to; --l) {                         // :291
+    RoctxRange range("up", l);
     Level& L = s->lv[l];
     Level& C = s->lv[l + 1];
     if (mc_patch_ok(s, l)) {  // :294-296 + :300 (colours 0,1 then 1,0), two launches

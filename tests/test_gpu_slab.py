@@ -98,10 +98,10 @@ def test_slab_cycle_equals_single_gpu_cycle(amg, patch_everywhere, world, max_le
     ref.close()
 
 
-@pytest.mark.parametrize("pmr,k", [(None, 4), (0, 6)])
+@pytest.mark.parametrize("pmr,k", [(None, 5), (0, 6)])
 def test_slab_full_size_4096_eight_ranks(amg, pmr, k):
     """BASELINE config 3 cut into 8 x 512 lines, all eight ranks' legs run one after the other on
-    this GPU: with the single-GPU K-Patch threshold (four slab levels, 23 halo lines) and the way
+    this GPU: with the single-GPU K-Patch threshold (10^6 rows: five slab levels, 29 halo lines) and the way
     bench.py --gpus 8 cuts it (--slab-patch-min-rows 0: six slab levels, 35 halo lines)."""
     n, L, world = 4096, 16, 8
     ref = amg.Multigrid.poisson(n, L, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
