@@ -128,6 +128,7 @@ _SIGS = {
     "amg_hip_fine_sweep_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _i32p, _f64p]),
     "amg_hip_set_patch_min_rows": (None, [C.c_int64]),
     "amg_hip_set_band_chain": (None, [C.c_int32]),
+    "amg_hip_set_tail_fusion": (None, [C.c_int32]),
     "amg_hip_set_patch_tile_flags": (None, [C.c_int32]),
     "amg_hip_create_rs": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_int32, C.c_double, C.c_int64,
                                     C.POINTER(Options), C.POINTER(C.c_void_p)]),
@@ -323,6 +324,10 @@ def slab_plan(lines, rank, world, levels):
 
 def set_patch_tile_flags(on):
     lib().amg_hip_set_patch_tile_flags(int(bool(on)))
+
+
+def set_tail_fusion(on):
+    lib().amg_hip_set_tail_fusion(int(bool(on)))
 
 
 def set_band_chain(on):

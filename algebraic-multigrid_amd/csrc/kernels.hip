@@ -1455,25 +1455,37 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_up_kernel(
   patch_copy_out<NT>(buf, u_out, n, m, j0, i0);
 }
 
-// ---- red-black Gauss-Seidel on a patch (multicolour smoother, 2-colour levels) ------------
-// One colour of a Gauss-Seidel half-sweep as a patch stage: cells of colour `cpar` inside the
+// ---- multicolour Gauss-Seidel on a patch (colours laid out on the 2 x 2 cells of the grid) ----
+// One colour of a Gauss-Seidel half-sweep as a patch stage: cells of colour `c` inside the
 // region take (f - sum of off-diagonal terms) / diagonal from the CURRENT neighbours (which all
-// have the other colour), every other cell keeps its value.  parbits: bit k = colour of cell k.
+// have other colours), every other cell keeps its value.  cbits: bits 2k, 2k+1 = colour of cell k.
 template <int UN, int UM>
 __device__ __forceinline__ void patch_stage_color(const PatchCells& pc, int ntypes, double* buf,
                                                   const PatchU& U, const PatchJ* tabJ, const PatchR* tabR,
-                                                  int l0, int l1, int c0, int c1, uint32_t parbits,
-                                                  uint32_t cpar) {
+                                                  int l0, int l1, int c0, int c1, uint32_t cbits,
+                                                  uint32_t c) {
   const bool inc = pc.li >= c0 && pc.li < c1;
   double res[PATCH_K];
   bool did[PATCH_K];
 #pragma unroll
   for (int k = 0; k < PATCH_K; ++k) {
     const int lj = pc.lj0 + k;
-    did[k] = inc && lj >= l0 && lj < l1 && pc.live[k] && ((parbits >> k) & 1u) == cpar;
+    did[k] = inc && lj >= l0 && lj < l1 && pc.live[k] && ((cbits >> (2 * k)) & 3u) == c;
   }
+  // A wave none of whose cells has the stage's colour has nothing to do (the colours of the line
+  // ends on level 1: almost every wave; -9 % on that level).  Otherwise every cell is evaluated and
+  // the other colours' results are dropped: evaluating only the lines that hold the colour (every
+  // other one, for the colourings by lines and by products) was measured no faster -- a stage is
+  // bound by its LDS round trips and barriers, not by the arithmetic -- and any finer branching
+  // (a ballot per cell) 35 % slower.
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < PATCH_K; ++k) any |= did[k];
+  if (__builtin_amdgcn_ballot_w64(any) == 0) return;
   if (pc.uniform && U.rmask == (uint32_t)UM) {
-    patch_eval_u<false, (UM & 0x145) != 0, true, (UM & 0x145) ? -1 : UM>(buf, pc.cell0, U, pc.f, 1.0, res);
+    constexpr bool CN = (UM & 0x145) != 0;
+    constexpr int MK = (UM & 0x145) ? -1 : UM;
+    patch_eval_u<false, CN, true, MK>(buf, pc.cell0, U, pc.f, 1.0, res);
   } else {
 #pragma unroll
     for (int k = 0; k < PATCH_K; ++k)
@@ -1486,20 +1498,27 @@ __device__ __forceinline__ void patch_stage_color(const PatchCells& pc, int ntyp
     if (did[k]) buf[pc.cell0 + k * PATCH_EC] = res[k];
 }
 
-// Two colour stages (first colour c_first, then the other) on the loaded patch -- half of the
-// symmetric pass 0,1,1,0 -- in the frame of the Jacobi kernels above:
-//   !TAIL: like the up-leg: [u + P u_H while loading when PROLONG], stage, stage, store;
-//    TAIL: like the level-0 down-leg: stage, stage, store, residual, restriction (f_H; the
+// Up to three colour stages on the loaded patch -- a piece of the symmetric pass 0 .. nc-1, nc-1 .. 0
+// (a colour that directly follows itself is dropped by the host: its rows read no row of their own
+// colour, so the repeat would write the bits that are already there) -- in the frame of the Jacobi
+// kernels above:
+//   !TAIL: like the up-leg: [u + P u_H while loading when PROLONG], up to 3 stages, store;
+//    TAIL: like the level-0 down-leg: up to 2 stages, store, residual, restriction (f_H; the
 //          coarse u is zeroed, multigrid.hpp:278).
-// colour(row) = ((row / m + row % m) & 1) ^ cb (the checkerboard the greedy colouring yields on
-// the 5-point level; verified on the host).  Same row arithmetic as the colour kernels
+// stages: bits 0-2 = number of stages, bits 4+2s, 5+2s = colour of stage s.
+// colour(row) = ctab entry (line & 1) * 6 + column class, 2 bits each; column classes: 0, 1, m-2,
+// m-1 (the line ends, whose rows differ) and the even / odd columns between them (what the greedy
+// colouring yields on these stencils: the checkerboard on the 5-point level; line parity with
+// colours of their own at the line ends on level 1, where only the lines above and below are
+// coupled; the product colouring on the 9-point levels -- verified on the host against the
+// colouring itself).  Same row arithmetic as the colour kernels
 // (dict_rows<CSR_GS>): ascending-column sum of the off-diagonal terms, IEEE divide.
 template <int UN, int UM, bool NT, bool PROLONG, bool TAIL>
 __global__ __launch_bounds__(PATCH_NT, 7) void patch_rb_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi, int nent, int ntypes,
     const double* x, const double* __restrict__ f, const double* __restrict__ uH, int nH, double* u_out,
-    double* r_out, double* __restrict__ fH, double* __restrict__ uH_zero, uint32_t c_first, uint32_t cb,
+    double* r_out, double* __restrict__ fH, double* __restrict__ uH_zero, uint32_t stages, uint32_t ctab,
     int xcd_map, int py0, const uint8_t* __restrict__ tflag) {
   __shared__ double buf[PATCH_BUF];
   __shared__ PatchJ tabJ[PATCH_MAXTAB];
@@ -1513,21 +1532,26 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_rb_kernel(
   if (tf != 255u) patch_load<PROLONG, true>(pc, tf, n, m, j0, i0, x, f, rtype, ntypes, uH, nH, buf);
   else patch_load<PROLONG, false>(pc, tf, n, m, j0, i0, x, f, rtype, ntypes, uH, nH, buf);
   patch_prologue(pc, buf, tabJ, tabR, ptab, nent, utabd, utabi, U);
-  uint32_t parbits = 0;
+  uint32_t cbits = 0;
   {
+    // the cell is flat row (j0 + lj) * m + i0 + li: beyond a line's end that is a row of the next / previous line
     const int col = i0 + pc.li;
-    const uint32_t base = (uint32_t)(j0 + pc.lj0 + col + ((col < 0 || col >= m) ? 1 : 0) + 64) ^ cb;
+    const uint32_t line = (uint32_t)(j0 + pc.lj0 + (col < 0 ? -1 : (col >= m ? 1 : 0)) + 64);
+    const int tc = col < 0 ? col + m : (col >= m ? col - m : col);
+    const uint32_t cls = tc == 0 ? 0u : (tc == 1 ? 1u : (tc == m - 2 ? 2u : (tc == m - 1 ? 3u : 4u + ((uint32_t)tc & 1u))));
 #pragma unroll
-    for (int k = 0; k < PATCH_K; ++k) parbits |= ((base + (uint32_t)k) & 1u) << k;
+    for (int k = 0; k < PATCH_K; ++k)
+      cbits |= ((ctab >> (2u * (((line + (uint32_t)k) & 1u) * 6u + cls))) & 3u) << (2 * k);
   }
   lds_barrier();
-  constexpr int E = TAIL ? 1 : 0;  // the residual stage needs one more ring
-  patch_stage_color<UN, UM>(pc, ntypes, buf, U, tabJ, tabR, -1 - E, PATCH_TH + 1 + E, -1 - E,
-                        PATCH_TW + 1 + 2 * E, parbits, c_first & 1u);
-  lds_barrier();
-  patch_stage_color<UN, UM>(pc, ntypes, buf, U, tabJ, tabR, -E, PATCH_TH + E, -E, PATCH_TW + 2 * E, parbits,
-                        (c_first & 1u) ^ 1u);
-  lds_barrier();
+  constexpr int E = TAIL ? 1 : 0;  // the residual stage needs one more ring (and the restriction one more column)
+  const int nst = (int)(stages & 7u);
+  for (int sg = 0; sg < nst; ++sg) {
+    const int ext = nst - 1 - sg + E;  // rings the later stages still read
+    patch_stage_color<UN, UM>(pc, ntypes, buf, U, tabJ, tabR, -ext, PATCH_TH + ext, -ext, PATCH_TW + ext + E,
+                              cbits, (stages >> (4 + 2 * sg)) & 3u);
+    lds_barrier();
+  }
   patch_copy_out<NT>(buf, u_out, n, m, j0, i0);
   if (TAIL) {
     patch_stage<UN, UM, true, NT, true>(pc, m, ntypes, buf, U, tabJ, tabR, 1.0, 0, PATCH_TH, 0, PATCH_TW + 1,
@@ -1622,12 +1646,23 @@ hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double
                        (int)nH, u_out, omega, xm, py0, P.tflag);
   });
 }
+// the halo a patch is loaded with (3 lines above and below, 4 columns left and right; the lines
+// beyond are guard lines of zeros) bounds the dependent stages of one launch: stage s of S reads
+// ring S - s, and the residual + restriction take a ring and a column of their own
+int patch_rb_max_stages(bool tail) { return tail ? 2 : 3; }
+uint32_t patch_rb_stages(const int* colors, int count) {
+  uint32_t v = (uint32_t)count & 7u;
+  for (int q = 0; q < count && q < 4; ++q) v |= ((uint32_t)colors[q] & 3u) << (4 + 2 * q);
+  return v;
+}
 hipError_t launch_patch_rb(bool prolong, bool tail, int64_t n, int64_t m, const PatchRef& P, const double* x,
                            const double* f, const double* uH, int64_t nH, double* u_out, double* r_out,
-                           double* fH, double* uH_zero, int c_first, int cb, hipStream_t st,
+                           double* fH, double* uH_zero, uint32_t stages, uint32_t ctab, hipStream_t st,
                            int64_t line_lo, int64_t line_hi) {
+  const int nst = (int)(stages & 7u);
   if (!patch_geometry_ok(n, m) || !P.rtype || !P.ptab || !P.utabd || !P.utabi || (P.ntypes + 1) * patch_un(P.un) > PATCH_MAXTAB ||
-      P.nent != P.ntypes * patch_un(P.un) || !u_out || u_out == x || (prolong && (!uH || tail)) || (tail && !fH) || nH < 2)
+      P.nent != P.ntypes * patch_un(P.un) || !u_out || u_out == x || (prolong && (!uH || tail)) || (tail && !fH) || nH < 2 ||
+      nst < 1 || nst > patch_rb_max_stages(tail) || (m & 1))
     return hipErrorInvalidValue;
   int pxc = 0, py0 = 0;
   const unsigned grid = patch_grid(n, m, line_lo, line_hi, &pxc, &py0);
@@ -1637,8 +1672,8 @@ hipError_t launch_patch_rb(bool prolong, bool tail, int64_t n, int64_t m, const 
 #define AMG_RB(PRO, TL)                                                                              \
   hipLaunchKernelGGL((patch_rb_kernel<decltype(U)::value, decltype(M)::value, decltype(NTF)::value, PRO, TL>), dim3(grid), \
                      dim3(PATCH_NT), 0, st, (int)n, (int)m, pxc, P.rtype, P.ptab, P.utabd, P.utabi,    \
-                     P.nent, P.ntypes, x, f, uH, (int)nH, u_out, r_out, fH, uH_zero, (uint32_t)c_first,  \
-                     (uint32_t)cb, xm, py0, P.tflag)
+                     P.nent, P.ntypes, x, f, uH, (int)nH, u_out, r_out, fH, uH_zero, stages, ctab, xm, py0,  \
+                     P.tflag)
     if (tail) AMG_RB(false, true);
     else if (prolong) AMG_RB(true, false);
     else AMG_RB(false, false);
@@ -3199,6 +3234,239 @@ hipError_t launch_band_chain(int64_t n, int w, const double* cf, const double* c
     case 1: hipLaunchKernelGGL(band_chain_kernel<1>, dim3(1), dim3(64), lds, st, (int)n, cf, cb, dg, f, x); break;
     case 2: hipLaunchKernelGGL(band_chain_kernel<2>, dim3(1), dim3(64), lds, st, (int)n, cf, cb, dg, f, x); break;
     default: hipLaunchKernelGGL(band_chain_kernel<3>, dim3(1), dim3(64), lds, st, (int)n, cf, cb, dg, f, x); break;
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ K-Tail -----
+// The deepest levels of a 2+2 true-Jacobi cycle in ONE launch of ONE workgroup (1024 threads),
+// with every vector of those levels RESIDENT IN LDS: the down-legs of the levels lt .. L-2 (second
+// pre-sweep, residual, restriction, first sweep of the next level), the coarsest solve
+// (K-BandChain's recurrence on wave 0), the prolongation out of the coarsest level, the up-legs back
+// to level lt and the prolongation into level lt - 1.  Every one of those steps is a launch of
+// 5-7 us otherwise -- and almost all of that is latency: the launch itself and two or three
+// dependent global round trips per step for a few thousand rows.  (A first form of this kernel
+// that kept the vectors in global memory and replayed the pair kernels tile by tile inside one
+// workgroup took 134 us for what eleven launches do in 70: the round trips, not the launches,
+// are the cost.)  Here a step is an LDS pass and a workgroup barrier: row types, tables, f and
+// the first-sweep result of level lt are staged once, everything else is produced in LDS; the
+// level vectors leave for global memory once, at the end (the getters and the finer level read
+// them there).  Same row arithmetic (dict_fetch / dict_rows on the same operands in the same
+// order), same transfer expressions, same recurrence: same bits.  All levels run with the widest
+// instantiation (two code words, nine slots); absent slots are no entries.
+constexpr int TAIL_MAX_LEVELS = TAIL_LEVELS_MAX;
+constexpr int TAIL_MAX_COARSE = 1024;
+constexpr int TAIL_LDS_DOUBLES = 18432;   // 147 456 B
+typedef TailLevelRef TailLevel;
+typedef TailRef TailArgs;
+int tail_max_coarse() { return TAIL_MAX_COARSE; }
+__host__ __device__ inline int tail_pad(int n) { return (n + 3) & ~1; }   // even, one spare entry
+// LDS layout in doubles: per level {U, F, tabJ (1024), tabR (1024), wtab (512), row types (n bytes)},
+// then T and R (scratch of the largest level), Uc, the chain arrays
+__host__ __device__ inline size_t tail_lds_doubles(const TailArgs& A) {
+  size_t d = 0;
+  int nmax = 0;
+  for (int q = 0; q < A.nlev; ++q) {
+    d += 2 * (size_t)tail_pad(A.L[q].n) + 1024 + 1024 + 512 + (size_t)((A.L[q].n + 15) / 16) * 2;
+    nmax = A.L[q].n > nmax ? A.L[q].n : nmax;
+  }
+  d += 2 * (size_t)tail_pad(nmax) + (size_t)tail_pad(A.nc) + (size_t)band_chain_pad(A.nc) * (size_t)(A.wc + 1);
+  return d;
+}
+// offsets (in doubles) into the kernel's one LDS array: pointers are formed from the array at
+// every use, so the compiler knows the address space (ds_ instructions, not flat ones)
+struct TailLds {
+  int U, F, tabJ, tabR, wtab, rt;
+};
+// out[row] = the MODE operation on rows [0, n) of the level, x / f / out in LDS
+template <int MODE>
+__device__ __forceinline__ void tail_rows(int n, const DictEntry* tab, const uint64_t* wtab, const uint8_t* rt,
+                                          const double* x, const double* f, double* out, double omega) {
+  for (int row0 = (int)threadIdx.x * 2; row0 < n; row0 += 2048) {
+    DictStream<2, 2> s;
+    dict_fetch<MODE, 2, false, 2>(s, row0, n, nullptr, rt, f, x, 0);
+    dict_expand<2, 2>(s, wtab);
+    double res[2];
+    dict_rows<MODE, 2, 9, 2>(s, row0, tab, x, omega, 0, res);
+    if (s.live[0]) out[row0] = res[0];
+    if (s.live[1]) out[row0 + 1] = res[1];
+  }
+}
+// out[i] = base[i] + (P uH)[i] for i in [0, n_h) (linear_prolong_add2_kernel)
+__device__ __forceinline__ void tail_prolong(int n_h, int n_H, const double* uH, const double* base, double* out) {
+  for (int j = threadIdx.x; 2 * j < n_h; j += 1024) {
+    const int i = 2 * j;
+    double t0 = 0.0, t1 = 0.0;
+    const double b = (j < n_H) ? uH[j] : 0.0;
+    if (j >= 1 && j - 1 < n_H) t0 += 0.5 * uH[j - 1];
+    if (j < n_H) {
+      t0 += 0.5 * b;
+      t1 += 1.0 * b;
+    }
+    out[i] = base[i] + t0;
+    if (i + 1 < n_h) out[i + 1] = base[i + 1] + t1;
+  }
+}
+template <int W>
+__global__ __launch_bounds__(1024) void tail_kernel(TailArgs A) {
+  __shared__ __attribute__((aligned(16))) double tail_lds[TAIL_LDS_DOUBLES];   // static: 144 KB of the CU's 160
+  TailLds P[TAIL_MAX_LEVELS];
+  int p = 0, nmax = 0;
+  for (int q = 0; q < A.nlev; ++q) {
+    const int n = A.L[q].n, np = tail_pad(n);
+    P[q].U = p; p += np;
+    P[q].F = p; p += np;
+    P[q].tabJ = p; p += 1024;
+    P[q].tabR = p; p += 1024;
+    P[q].wtab = p; p += 512;
+    P[q].rt = p; p += ((n + 15) / 16) * 2;
+    nmax = n > nmax ? n : nmax;
+  }
+  double* const T = tail_lds + p; p += tail_pad(nmax);
+  double* const R = tail_lds + p; p += tail_pad(nmax);
+  const int Uc = p; p += tail_pad(A.nc);
+  const int npc = band_chain_pad(A.nc);
+  double* const ops = tail_lds + p;      // npc x W
+  const int voff = p + npc * W;
+  double* const v = tail_lds + voff;     // npc: coarsest right-hand side in step order, then the result
+  if (voff + npc > TAIL_LDS_DOUBLES) return;   // launch_tail refuses such a hierarchy; never reached
+  const double omega = A.omega;
+  const int tid = (int)threadIdx.x;
+#define TAIL_D(off) (tail_lds + (off))
+#define TAIL_TAB(off) reinterpret_cast<DictEntry*>(tail_lds + (off))
+#define TAIL_W(off) reinterpret_cast<uint64_t*>(tail_lds + (off))
+#define TAIL_B(off) reinterpret_cast<uint8_t*>(tail_lds + (off))
+  // ---- stage: tables and row types of every level, f and the first-sweep result of level lt, the
+  // forward operands of the coarsest factor -- all requested before the first wait ----
+  for (int q = 0; q < A.nlev; ++q) {
+    const TailLevel& L = A.L[q];
+    if (tid < 256) {
+      const int t = tid;
+      const double val = t < L.ntab ? L.dval[t] : 0.0;
+      const int32_t o = t < L.ntab ? L.doff[t] : 0;
+      DictEntry e;
+      e.a = o == 0 ? 0.0 : val;                    // dict_stage_table<CSR_JACOBI>
+      e.d = (o == 0 && t < L.ntab) ? val : 0.0;
+      e.off8 = o * 8;
+      e.pad[0] = e.pad[1] = e.pad[2] = 0;
+      TAIL_TAB(P[q].tabJ)[t] = e;
+      e.a = val;                                   // dict_stage_table<CSR_RESID>
+      e.d = 0.0;
+      TAIL_TAB(P[q].tabR)[t] = e;
+      TAIL_W(P[q].wtab)[2 * t] = L.rwords[(size_t)t * L.words];
+      TAIL_W(P[q].wtab)[2 * t + 1] = L.words == 2 ? L.rwords[(size_t)t * 2 + 1] : ~(uint64_t)0;
+    }
+    for (int r = tid; r < ((L.n + 15) / 16) * 16; r += 1024) TAIL_B(P[q].rt)[r] = r < L.n ? L.rtype[r] : (uint8_t)255;
+  }
+  for (int r = tid; r < tail_pad(A.L[0].n); r += 1024) {
+    TAIL_D(P[0].F)[r] = r < A.L[0].n ? A.L[0].f[r] : 0.0;
+    T[r] = r < A.L[0].n ? A.L[0].tmp[r] : 0.0;
+  }
+  for (int k = tid; k < npc * W; k += 1024) ops[k] = k < A.nc * W ? A.cf[k] : 0.0;
+  __syncthreads();
+  // ---- down-legs (multigrid.hpp:265-283) ----
+  for (int li = 0; li < A.nlev; ++li) {
+    const int n = A.L[li].n;
+    const bool last = li + 1 == A.nlev;
+    const int nH = last ? A.nc : A.L[li + 1].n;
+    const double* dH = last ? A.diagc : A.L[li + 1].diag;
+    const TailLds Q = P[li];
+    tail_rows<CSR_JACOBI>(n, TAIL_TAB(Q.tabJ), TAIL_W(Q.wtab), TAIL_B(Q.rt), T, TAIL_D(Q.F), TAIL_D(Q.U),
+                          omega);                                          // second pre-sweep (T = the first)
+    __syncthreads();
+    tail_rows<CSR_RESID>(n, TAIL_TAB(Q.tabR), TAIL_W(Q.wtab), TAIL_B(Q.rt), TAIL_D(Q.U), TAIL_D(Q.F), R,
+                         omega);                                           // r = f - A u
+    if (tid < 2) R[n + tid] = 0.0;
+    __syncthreads();
+    double* FH = TAIL_D(last ? voff : P[li + 1 < A.nlev ? li + 1 : li].F);
+    for (int j = tid; j < nH; j += 1024) {                                // linear_restrict_kernel + jacobi_from_zero
+      const int i = 2 * j;
+      double sum = 0.0;
+      if (i < n) sum += 0.5 * R[i];
+      if (i + 1 < n) sum += 1.0 * R[i + 1];
+      if (i + 2 < n) sum += 0.5 * R[i + 2];
+      FH[j] = sum;
+      const double xi = 0.0, acc = 0.0;
+      const double d = dH[j];
+      T[j] = (d == 0.0) ? xi : xi + omega * ((sum - acc) / d - xi);
+    }
+    if (last)
+      for (int j = nH + tid; j < npc; j += 1024) v[j] = 0.0;
+    __syncthreads();
+  }
+  // ---- coarsest solve (multigrid.hpp:287-288): band_chain_kernel, wave 0 walks the recurrence ----
+  {
+    const int n = A.nc;
+    if (tid >= 64)   // the level's right-hand side and first sweep go home while wave 0 solves
+      for (int j = tid - 64; j < n; j += 960) {
+        A.fc[j] = v[j];
+        A.tmpc[j] = T[j];
+      }
+    __syncthreads();
+    if (tid < 64) band_chain_pass<W>(n, ops, v);       // L y = f
+    __syncthreads();
+    double z = 0.0;
+    if (tid < n) z = v[n - 1 - tid] / A.dg[n - 1 - tid];
+    for (int k = tid; k < n * W; k += 1024) ops[k] = A.cb[k];
+    __syncthreads();
+    if (tid < n) v[tid] = z;
+    __syncthreads();
+    if (tid < 64) band_chain_pass<W>(n, ops, v);       // L^T x = z, step s = row n-1-s
+    __syncthreads();
+    if (tid < n) {
+      const double x = v[tid];
+      TAIL_D(Uc)[n - 1 - tid] = x;
+      A.uc[n - 1 - tid] = x;
+    }
+    __syncthreads();
+  }
+  // ---- up-legs (multigrid.hpp:291-302) ----
+  int uH = Uc;
+  int nH = A.nc;
+  for (int li = A.nlev - 1; li >= 0; --li) {
+    const int n = A.L[li].n;
+    const TailLds Q = P[li];
+    tail_prolong(n, nH, TAIL_D(uH), TAIL_D(Q.U), T);                       // T = u + P u_H
+    __syncthreads();
+    tail_rows<CSR_JACOBI>(n, TAIL_TAB(Q.tabJ), TAIL_W(Q.wtab), TAIL_B(Q.rt), T, TAIL_D(Q.F), R, omega);
+    __syncthreads();
+    tail_rows<CSR_JACOBI>(n, TAIL_TAB(Q.tabJ), TAIL_W(Q.wtab), TAIL_B(Q.rt), R, TAIL_D(Q.F), TAIL_D(Q.U), omega);
+    __syncthreads();
+    uH = Q.U;
+    nH = n;
+  }
+  // ---- the prolongation into level lt - 1, and the level vectors go home ----
+  tail_prolong(A.n_fine, nH, TAIL_D(uH), A.uf_in, A.uf_out);
+  for (int li = 0; li < A.nlev; ++li) {
+    const TailLevel& L = A.L[li];
+    for (int r = tid; r < L.n; r += 1024) {
+      L.u[r] = TAIL_D(P[li].U)[r];
+      if (li > 0) const_cast<double*>(L.f)[r] = TAIL_D(P[li].F)[r];
+    }
+  }
+#undef TAIL_D
+#undef TAIL_TAB
+#undef TAIL_W
+#undef TAIL_B
+}
+bool tail_level_ok(int64_t n, const DictRef& D, int hb) {
+  return D.rtype && D.rwords && !D.nt && hb >= 0 && n >= 256 && n <= 4095 && D.wmax <= 9 && D.words >= 1 &&
+         D.words <= 2 && D.ntab <= 255;
+}
+size_t tail_lds_bytes(const TailRef& A) { return sizeof(double) * tail_lds_doubles(A); }
+size_t tail_lds_capacity() { return sizeof(double) * (size_t)TAIL_LDS_DOUBLES; }
+hipError_t launch_tail(const TailArgs& A, hipStream_t st) {
+  if (A.nlev < 1 || A.nlev > TAIL_MAX_LEVELS || A.nc < 1 || A.nc > TAIL_MAX_COARSE || !band_chain_ok(A.nc, A.wc) ||
+      tail_lds_bytes(A) > tail_lds_capacity() || A.n_fine < 1 || !A.uf_in || !A.uf_out)
+    return hipErrorInvalidValue;
+  for (int q = 0; q < A.nlev; ++q)
+    if (A.L[q].n < 2 || !A.L[q].rtype || !A.L[q].rwords || !A.L[q].doff || !A.L[q].dval || !A.L[q].f || !A.L[q].u ||
+        !A.L[q].tmp || !A.L[q].diag || A.L[q].ntab < 1 || A.L[q].ntab > 255)
+      return hipErrorInvalidValue;
+  switch (A.wc) {
+    case 1: hipLaunchKernelGGL(tail_kernel<1>, dim3(1), dim3(1024), 0, st, A); break;
+    case 2: hipLaunchKernelGGL(tail_kernel<2>, dim3(1), dim3(1024), 0, st, A); break;
+    default: hipLaunchKernelGGL(tail_kernel<3>, dim3(1), dim3(1024), 0, st, A); break;
   }
   return hipGetLastError();
 }

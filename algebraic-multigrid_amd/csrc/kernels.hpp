@@ -82,6 +82,39 @@ hipError_t launch_dict_pair_down(int64_t n, const DictRef& D, int hb, const doub
 hipError_t launch_dict_pair_up(int64_t n, const DictRef& D, int hb, const double* a,
                                const double* f, double* u_out, double omega, int64_t n_h,
                                const double* uh_in, double* uh_out, hipStream_t st);
+// K-Tail (kernels.hip): the deepest levels of the 2+2 true-Jacobi cycle -- down-legs of levels
+// lt .. L-2, the coarsest solve (K-BandChain operands), up-legs and the prolongation into level
+// lt - 1 -- in ONE launch of one workgroup.
+constexpr int TAIL_LEVELS_MAX = 6;
+struct TailLevelRef {
+  int n, hbw, words, ntab;
+  const uint8_t* rtype;
+  const uint64_t* rwords;
+  const int32_t* doff;
+  const double* dval;
+  const double* f;
+  double* u;
+  double* tmp;
+  const double* diag;
+};
+struct TailRef {
+  int nlev;
+  TailLevelRef L[TAIL_LEVELS_MAX];
+  int nc, wc;
+  const double *cf, *cb, *dg;
+  double *fc, *uc, *tmpc;
+  const double* diagc;
+  int n_fine;
+  const double* uf_in;
+  double* uf_out;
+  double omega;
+};
+bool tail_level_ok(int64_t n, const DictRef& D, int hb);
+int tail_max_coarse();
+size_t tail_lds_bytes(const TailRef& A);  // LDS the level vectors, tables and the coarsest factor need
+size_t tail_lds_capacity();               // ... and what the kernel has (static: 144 KB)
+hipError_t launch_tail(const TailRef& A, hipStream_t st);
+
 // K-Patch (kernels.hip): a level's whole down-leg / up-leg of the 2+2 true-Jacobi cycle in
 // one launch over 2-D patches of the level (temporal blocking).  ptab: per (row type, slot)
 // {off-diagonal value or +0.0, diagonal value or +0.0, value, LDS offset dj * pitch + di or
@@ -128,13 +161,16 @@ int patch_tile_lines();
 hipError_t launch_patch_up(int64_t n, int64_t m, const PatchRef& P, const double* x, const double* f,
                            const double* uH, int64_t nH, double* u_out, double omega,
                            hipStream_t st, int64_t line_lo = 0, int64_t line_hi = -1);
-// Red-black Gauss-Seidel on patches (2-colour levels of the multicolour smoother): two colour
-// stages, first colour c_first then the other, u_out != x.  prolong: the input is x + P uH;
+// Multicolour Gauss-Seidel on patches: up to patch_rb_max_stages(tail) colour stages per launch
+// (stages = patch_rb_stages(colours, count)), u_out != x.  prolong: the input is x + P uH;
 // tail: followed by the residual (r_out optional), the restriction into fH and the zeroing of
-// uH_zero (optional).  colour(row) = ((row / m + row % m) & 1) ^ cb.
+// uH_zero (optional).  colour(row) = 2-bit entry ((row / m) & 1) * 6 + column class of ctab; column
+// classes of c = row % m: 0: c == 0, 1: c == 1, 2: c == m-2, 3: c == m-1, else 4 + (c & 1).
+int patch_rb_max_stages(bool tail);
+uint32_t patch_rb_stages(const int* colors, int count);
 hipError_t launch_patch_rb(bool prolong, bool tail, int64_t n, int64_t m, const PatchRef& P, const double* x,
                            const double* f, const double* uH, int64_t nH, double* u_out, double* r_out,
-                           double* fH, double* uH_zero, int c_first, int cb, hipStream_t st,
+                           double* fH, double* uH_zero, uint32_t stages, uint32_t ctab, hipStream_t st,
                            int64_t line_lo = 0, int64_t line_hi = -1);
 // uh_out = uh_in + P uH for the linear interpolation pair (16-byte aligned vectors)
 hipError_t launch_linear_prolong_to(int64_t n_h, int64_t n_H, const double* uH,

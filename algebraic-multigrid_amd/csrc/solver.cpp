@@ -782,7 +782,11 @@ struct Level {
   int scan_C = 0, scan_ring = 0;  // > 0: the lexicographic sweeps run as K-GS-scan
   // multicolour: colour-permuted SELL-64 copy + dof of every storage row
   std::vector<int32_t> color;
-  int mc_checker = -1;  // 2 colours laid out as the checkerboard of the level's 2-D band: colour of row 0, else -1
+  // <= 4 colours that are a function of (line parity, column class) on the level's 2-D band: the table
+  // as 2-bit entries (line & 1) * 6 + class, else -1 (kernels.hip: patch_rb_kernel; classes: the
+  // columns 0, 1, m-2, m-1 and the even / odd columns between them)
+  int mc_ctab = -1;
+  DevMem mc_aux;  // third vector of the patch colour stages when r is kept (opt.keep_residual)
   int32_t n_colors = 0;
   DevMat mc_mat;
   DevMem mc_rowid;
@@ -819,6 +823,13 @@ struct Slab {
   }
 };
 
+// amg_hip_set_tail_fusion / AMG_HIP_TAIL_FUSION=1: K-Tail (deepest levels + coarsest solve in one
+// launch).  Off by default: bit-identical, and measured 0.5 % SLOWER than one launch per step on the
+// 4096^2 cycle (1282 / 1291 / 1293 against 1299 / 1301 / 1294 V-cycles/s, alternating runs).
+int g_tail_fusion = [] {
+  const char* e = std::getenv("AMG_HIP_TAIL_FUSION");
+  return (e && *e == '1') ? 1 : 0;
+}();
 int64_t g_patch_min_rows = 1000000;  // amg_hip_set_patch_min_rows (level 4 of 4096^2 has 1 048 575 rows)
 
 struct amg_hip_solver {
@@ -862,7 +873,7 @@ double mat_bytes(const DevMat& A) {
 }
 
 // ---- smoother on one level --------------------------------------------------
-amg_hip_status enqueue_multicolor(amg_hip_solver* s, Level& L, hipStream_t st);
+amg_hip_status enqueue_multicolor(amg_hip_solver* s, Level& L, hipStream_t st, bool again);
 
 // phase 0: u_l is arbitrary.  phase 1: u_l is known to be zero (pre-smoothing of a
 // coarse level, multigrid.hpp:278).  phase 2: u_l still lacks the correction
@@ -906,15 +917,77 @@ bool patch_level_ok(const amg_hip_solver* s, int l) {
   return l == 0 || patch_level_ok(s, l - 1);
 }
 
-// Multicolour smoother on a 2-colour (checkerboard) level: the symmetric pass as patch stages,
-// the residual + restriction and the prolongation fused into them (kernels.hip: patch_rb_kernel)
+// Multicolour smoother on a level whose colours repeat on the 2 x 2 cells of its 2-D band (the
+// checkerboard of the 5-point level, line parity, the product colouring of the 9-point levels): the
+// symmetric passes as patch stages, the residual + restriction and the prolongation fused into them
+// (kernels.hip: patch_rb_kernel)
 bool mc_patch_ok(const amg_hip_solver* s, int l) {
   if (l < 0 || l + 1 >= (int)s->lv.size()) return false;
   const Level& L = s->lv[l];
   const DevMat& A = L.A_rows;
-  return s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS && s->opt.smoother_iters == 1 && !s->opt.no_fusion &&
+  return s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS && s->opt.smoother_iters >= 1 && !s->opt.no_fusion &&
          L.symmetric && A.dict && A.dict_shift == 0 && A.patch && L.linear && s->opt.stencil_transfers &&
-         L.n >= s->patch_min_rows && L.mc_checker >= 0 && s->lv[l + 1].n >= 2;
+         L.n >= s->patch_min_rows && L.mc_ctab >= 0 && s->lv[l + 1].n >= 2 &&
+         (!s->opt.keep_residual || L.mc_aux.p != nullptr);
+}
+// The colour stages of smoother_iters symmetric passes (0 .. nc-1, nc-1 .. 0 each).  A colour that
+// directly follows itself is dropped: its rows read no row of their own colour (that is what the
+// colouring means; explicit zeros add +-0.0), so the repeat would store the bits already there.
+static std::vector<int> mc_sequence(int nc, int iters) {
+  std::vector<int> q;
+  for (int it = 0; it < iters; ++it) {
+    for (int c = 0; c < nc; ++c)
+      if (q.empty() || q.back() != c) q.push_back(c);
+    for (int c = nc - 1; c >= 0; --c)
+      if (q.back() != c) q.push_back(c);
+  }
+  return q;
+}
+// The launches of one level and cycle in the patch form: the down-leg (the last launch carries the
+// residual + restriction and at most patch_rb_max_stages(true) stages), then the up-leg (the first
+// launch prolongs while loading).  A launch cannot write the vector it reads (tiles overlap), so
+// the level vector travels u -> tmp -> r -> tmp ... -> u (r, or mc_aux when r is kept).
+struct McLaunch {
+  uint32_t stages = 0;
+  bool prolong = false, tail = false;
+  double *in = nullptr, *out = nullptr;
+};
+static std::vector<McLaunch> mc_plan(amg_hip_solver* s, int l, int* n_down) {
+  Level& L = s->lv[l];
+  const std::vector<int> q = mc_sequence(L.n_colors, s->opt.smoother_iters);
+  const int n = (int)q.size();
+  std::vector<McLaunch> P;
+  auto chunks = [&](int from, int count, int cap, bool prolong_first) {
+    if (count <= 0) return;
+    const int k = (count + cap - 1) / cap;
+    int at = from;
+    for (int c = 0; c < k; ++c) {
+      const int len = count / k + (c < count % k ? 1 : 0);
+      McLaunch M;
+      M.stages = patch_rb_stages(q.data() + at, len);
+      M.prolong = prolong_first && c == 0;
+      P.push_back(M);
+      at += len;
+    }
+  };
+  const int tail_cnt = std::min(n, patch_rb_max_stages(true));
+  chunks(0, n - tail_cnt, patch_rb_max_stages(false), false);
+  {
+    McLaunch M;
+    M.stages = patch_rb_stages(q.data() + (n - tail_cnt), tail_cnt);
+    M.tail = true;
+    P.push_back(M);
+  }
+  *n_down = (int)P.size();
+  chunks(0, n, patch_rb_max_stages(false), true);
+  double* third = s->opt.keep_residual ? L.mc_aux.as<double>() : L.r.as<double>();
+  double* cur = L.u.as<double>();
+  for (size_t i = 0; i < P.size(); ++i) {
+    P[i].in = cur;
+    P[i].out = i + 1 == P.size() ? L.u.as<double>() : ((i & 1) ? third : L.tmp.as<double>());
+    cur = P[i].out;
+  }
+  return P;
 }
 
 // up: last post-smoothing sweep of level l+1 + prolongation into level l
@@ -939,6 +1012,35 @@ bool pair_level_ok(const amg_hip_solver* s, int l) {
 }
 bool pair_up_ok(const amg_hip_solver* s, int l) {  // its second sweep prolongs into level l-1
   return pair_level_ok(s, l) && fuses_jacobi_prolong(s, l - 1);
+}
+
+// K-Tail: first level lt such that the levels lt .. L-2, the coarsest solve and the prolongation
+// into lt - 1 run as ONE launch (kernels.hip: tail_kernel), or -1.
+int tail_from(const amg_hip_solver* s) {
+  const int nl = (int)s->lv.size();
+  if (!g_tail_fusion || s->opt.keep_residual || s->opt.window || nl < 3 || s->coarse.kind != COARSE_CHAIN ||
+      s->coarse.n > tail_max_coarse())
+    return -1;
+  int lt = nl - 1;
+  while (lt - 1 >= 1 && nl - 1 - (lt - 1) <= TAIL_LEVELS_MAX) {
+    const int l = lt - 1;
+    const Level& L = s->lv[l];
+    if (!(pair_level_ok(s, l) && pair_up_ok(s, l) && tail_level_ok(L.n, L.A_rows.dict_ref(), L.A_rows.dict_hb) &&
+          L.diag.p && s->lv[l + 1].diag.p))
+      break;
+    lt = l;
+  }
+  // the level vectors live in LDS: drop levels from the top until the launch fits
+  for (; lt <= nl - 2; ++lt) {
+    TailRef T;
+    std::memset(&T, 0, sizeof(T));
+    T.nlev = nl - 1 - lt;
+    for (int q = 0; q < T.nlev; ++q) T.L[q].n = (int)s->lv[lt + q].n;
+    T.nc = (int)s->coarse.n;
+    T.wc = (int)s->coarse.w;
+    if (tail_lds_bytes(T) <= tail_lds_capacity()) return lt;
+  }
+  return -1;
 }
 
 // phase 3: the first sweep was already done by the fused kernel of the finer level
@@ -1027,7 +1129,7 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
     }
     case AMG_HIP_SM_MULTICOLOR_GS:
       for (int it = 0; it < iters; ++it) {
-        amg_hip_status r = enqueue_multicolor(s, L, st);
+        amg_hip_status r = enqueue_multicolor(s, L, st, it > 0);
         if (r != AMG_HIP_OK) return r;
       }
       return AMG_HIP_OK;
@@ -1035,20 +1137,25 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
   return fail(AMG_HIP_EINVAL, "unknown smoother kind");
 }
 
-// one symmetric pass: colours 0..nc-1 then nc-1..0
-amg_hip_status enqueue_multicolor(amg_hip_solver* s, Level& L, hipStream_t st) {
+// one symmetric pass: colours 0..nc-1 then nc-1..0; a colour that directly follows itself is not
+// launched again (mc_sequence: the repeat would store the bits already there).  again: the pass
+// follows another pass of the same smoothing call (its colour 0 directly follows colour 0).
+amg_hip_status enqueue_multicolor(amg_hip_solver* s, Level& L, hipStream_t st, bool again) {
   const DevMat& A = L.mc_mat;
-  // one symmetric pass = every row twice: matrix stream (dictionary: code words 8 B per word and
-  // row + 4 B dof id; SELL panels: indices + values + 4 B dof id), f, u written
-  s->acct(2.0 * ((L.mc_dict ? (8.0 * L.mc_words + 4.0) * L.n : mat_bytes(A) + 4.0 * L.n) + 16.0 * L.n));
   if (L.mc_dict && L.mc_start_dev.p && !s->opt.no_fusion) {  // small level: the whole pass in one launch
+    // every row twice: code words 8 B per word and row + 4 B dof id, f, u written
+    s->acct(2.0 * ((8.0 * L.mc_words + 4.0) * L.n + 16.0 * L.n));
     HIP_TRY(launch_dict_gs_sweep(L.n_colors, L.mc_start_dev.as<int32_t>(), L.mc_start.back(), L.mc_words,
                                  L.mc_wmax, L.mc_codes.as<uint64_t>(), L.mc_rowid.as<int32_t>(),
                                  L.mc_doff.as<int32_t>(), L.mc_dval.as<double>(), L.mc_ntab,
                                  L.f.as<double>(), L.u.as<double>(), st));
     return AMG_HIP_OK;
   }
+  // per row of a launched colour: matrix stream (dictionary: code words + 4 B dof id; SELL panels:
+  // indices + values + 4 B dof id), f, u written
+  const double row_bytes = (L.mc_dict ? 8.0 * L.mc_words + 4.0 : (mat_bytes(A) + 4.0 * L.n) / (double)std::max<int64_t>(L.n, 1)) + 16.0;
   auto one = [&](int c) -> hipError_t {
+    s->acct(row_bytes * (double)(L.mc_start[c + 1] - L.mc_start[c]));
     if (L.mc_dict)
       return launch_dict_gs_color(L.mc_start[c], L.mc_start[c + 1] - L.mc_start[c], L.mc_words,
                                   L.mc_wmax, L.mc_codes.as<uint64_t>(), L.mc_rowid.as<int32_t>(),
@@ -1059,8 +1166,9 @@ amg_hip_status enqueue_multicolor(amg_hip_solver* s, Level& L, hipStream_t st) {
                                 L.mc_start[c + 1] - L.mc_start[c], L.f.as<double>(),
                                 L.u.as<double>(), st);
   };
-  for (int c = 0; c < L.n_colors; ++c) HIP_TRY(one(c));
-  for (int c = L.n_colors - 1; c >= 0; --c) HIP_TRY(one(c));
+  const bool dedupe = !s->opt.no_fusion;
+  for (int c = (again && dedupe) ? 1 : 0; c < L.n_colors; ++c) HIP_TRY(one(c));
+  for (int c = L.n_colors - (dedupe ? 2 : 1); c >= 0; --c) HIP_TRY(one(c));
   return AMG_HIP_OK;
 }
 
@@ -1130,6 +1238,8 @@ amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
   const bool ranged = part == CYCLE_SLAB_DOWN || part == CYCLE_SLAB_UP;
   const bool zero_known = jacobi_fuses_zero(s);  // coarse pre-smoothing starts from u == 0
   bool first_sweep_done = false;  // by the fused residual+restrict kernel of level l-1
+  const int tail_lt = (part == CYCLE_ALL || part == CYCLE_SLAB_TAIL) ? tail_from(s) : -1;
+  bool tail_done = false;
   if (part == CYCLE_SLAB_TAIL) {
     Level& L = s->lv[k];
     HIP_TRY(launch_jacobi_from_zero(L.n, L.diag.as<double>(), L.f.as<double>(), L.tmp.as<double>(),
@@ -1145,17 +1255,21 @@ amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
     // u with the direct solve of the level's rhs (multigrid.hpp:268-274, :287-288): unless
     // the residual is to be kept, neither has an observable effect.
     if (l == nl - 1 && nl > 1 && !s->opt.keep_residual) break;
-    if (mc_patch_ok(s, l)) {  // :268 (colours 0,1 then 1,0) + :272-282, two launches
+    if (mc_patch_ok(s, l)) {  // :268 (the colour stages of the symmetric passes) + :272-282
       Level& L = s->lv[l];
       Level& C = s->lv[l + 1];
       const DevMat& A = L.A_rows;
-      HIP_TRY(launch_patch_rb(false, false, L.n, A.patch_m, A.patch_ref(), L.u.as<double>(), L.f.as<double>(),
-                              nullptr, C.n, L.tmp.as<double>(), nullptr, nullptr, nullptr, 0, L.mc_checker, st));
-      HIP_TRY(launch_patch_rb(false, true, L.n, A.patch_m, A.patch_ref(), L.tmp.as<double>(), L.f.as<double>(),
-                              nullptr, C.n, L.u.as<double>(), s->opt.keep_residual ? L.r.as<double>() : nullptr,
-                              C.f.as<double>(), C.u.as<double>(), 1, L.mc_checker, st));
-      // each launch: row types + x + f + out; the second also f_H, zeroed u_H (and r when kept)
-      s->acct(2.0 * 25.0 * L.n + 16.0 * C.n + (s->opt.keep_residual ? 8.0 * L.n : 0.0));
+      int nd = 0;
+      const std::vector<McLaunch> plan = mc_plan(s, l, &nd);
+      for (int q = 0; q < nd; ++q) {
+        const McLaunch& M = plan[(size_t)q];
+        HIP_TRY(launch_patch_rb(false, M.tail, L.n, A.patch_m, A.patch_ref(), M.in, L.f.as<double>(), nullptr, C.n,
+                                M.out, (M.tail && s->opt.keep_residual) ? L.r.as<double>() : nullptr,
+                                M.tail ? C.f.as<double>() : nullptr, M.tail ? C.u.as<double>() : nullptr, M.stages,
+                                (uint32_t)L.mc_ctab, st));
+      }
+      // each launch: row types + x + f + out; the last also f_H, zeroed u_H (and r when kept)
+      s->acct(nd * 25.0 * L.n + 16.0 * C.n + (s->opt.keep_residual ? 8.0 * L.n : 0.0));
       first_sweep_done = false;
       continue;
     }
@@ -1182,6 +1296,52 @@ amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
       }
       first_sweep_done = true;
       continue;
+    }
+    if (first_sweep_done && l == tail_lt) {  // levels l .. L-2, the solve and the way back: ONE launch
+      TailRef T;
+      std::memset(&T, 0, sizeof(T));
+      T.nlev = nl - 1 - l;
+      for (int q = 0; q < T.nlev; ++q) {
+        Level& Q = s->lv[l + q];
+        const DictRef D = Q.A_rows.dict_ref();
+        TailLevelRef& R = T.L[q];
+        R.n = (int)Q.n;
+        R.hbw = (Q.A_rows.dict_hb + 1) & ~1;
+        R.words = D.words;
+        R.ntab = D.ntab;
+        R.rtype = D.rtype;
+        R.rwords = D.rwords;
+        R.doff = D.doff;
+        R.dval = D.dval;
+        R.f = Q.f.as<double>();
+        R.u = Q.u.as<double>();
+        R.tmp = Q.tmp.as<double>();
+        R.diag = Q.diag.as<double>();
+      }
+      Level& C = s->lv[nl - 1];
+      T.nc = (int)C.n;
+      T.wc = (int)s->coarse.w;
+      T.cf = s->coarse.sf.as<double>();
+      T.cb = s->coarse.sb.as<double>();
+      T.dg = s->coarse.d.as<double>();
+      T.fc = C.f.as<double>();
+      T.uc = C.u.as<double>();
+      T.tmpc = C.tmp.as<double>();
+      T.diagc = C.diag.as<double>();
+      Level& F = s->lv[l - 1];
+      T.n_fine = (int)F.n;
+      T.uf_in = F.u.as<double>();
+      T.uf_out = pair_up_ok(s, l - 1) ? F.tmp.as<double>() : F.u.as<double>();
+      T.omega = s->opt.omega;
+      HIP_TRY(launch_tail(T, st));
+      for (int q = 0; q < T.nlev; ++q) {  // what the pair kernels of these levels would have moved
+        const Level& Q = s->lv[l + q];
+        const double nH = (double)s->lv[l + q + 1].n, nF = (double)s->lv[l + q - 1].n;
+        s->acct(2.0 * (mat_bytes(Q.A_rows) + 24.0 * Q.n) + 24.0 * nH + 16.0 * nF);
+      }
+      s->acct(16.0 * (double)C.n * (double)std::max<int64_t>(s->coarse.w, 1) + 24.0 * C.n);
+      tail_done = true;
+      break;
     }
     if (first_sweep_done && pair_level_ok(s, l)) {  // second pre-sweep + residual + restriction
       Level& L = s->lv[l];
@@ -1236,7 +1396,7 @@ amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
       }
     }
   }
-  if (!ranged) {                                                   // :287-288
+  if (!ranged && !tail_done) {                                     // :287-288
     RoctxRange range("coarse solve", -1);
     if (s->opt.window)
       return fail(AMG_HIP_EINVAL, "a window solver (opt.window) runs by parts: amg_hip_window_run");
@@ -1251,20 +1411,23 @@ amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
   auto up_target = [&](int l) -> double* {
     return pair_up_ok(s, l) ? s->lv[l].tmp.as<double>() : s->lv[l].u.as<double>();
   };
-  const int up_from = part == CYCLE_SLAB_UP ? k - 1 : (part == CYCLE_SLAB_DOWN ? -1 : nl - 2);
+  const int up_from = part == CYCLE_SLAB_UP ? k - 1 : (part == CYCLE_SLAB_DOWN ? -1 : (tail_done ? tail_lt - 1 : nl - 2));
   const int up_to = part == CYCLE_SLAB_TAIL ? k : 0;
   for (int l = up_from; l >= up_to; --l) {                         // :291
     RoctxRange range("up", l);
     Level& L = s->lv[l];
     Level& C = s->lv[l + 1];
-    if (mc_patch_ok(s, l)) {  // :294-296 + :300 (colours 0,1 then 1,0), two launches
+    if (mc_patch_ok(s, l)) {  // :294-296 + :300 (the colour stages of the symmetric passes)
       const DevMat& A = L.A_rows;
-      HIP_TRY(launch_patch_rb(true, false, L.n, A.patch_m, A.patch_ref(), L.u.as<double>(), L.f.as<double>(),
-                              C.u.as<double>(), C.n, L.tmp.as<double>(), nullptr, nullptr, nullptr, 0,
-                              L.mc_checker, st));
-      HIP_TRY(launch_patch_rb(false, false, L.n, A.patch_m, A.patch_ref(), L.tmp.as<double>(), L.f.as<double>(),
-                              nullptr, C.n, L.u.as<double>(), nullptr, nullptr, nullptr, 1, L.mc_checker, st));
-      s->acct(2.0 * 25.0 * L.n + 8.0 * C.n);
+      int nd = 0;
+      const std::vector<McLaunch> plan = mc_plan(s, l, &nd);
+      for (size_t q = (size_t)nd; q < plan.size(); ++q) {
+        const McLaunch& M = plan[q];
+        HIP_TRY(launch_patch_rb(M.prolong, false, L.n, A.patch_m, A.patch_ref(), M.in, L.f.as<double>(),
+                                M.prolong ? C.u.as<double>() : nullptr, C.n, M.out, nullptr, nullptr, nullptr,
+                                M.stages, (uint32_t)L.mc_ctab, st));
+      }
+      s->acct((double)(plan.size() - (size_t)nd) * 25.0 * L.n + 8.0 * C.n);
       continue;
     }
     if (patch_level_ok(s, l)) {  // :294-296 + :300 (both sweeps), one launch
@@ -1569,15 +1732,31 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
       HIP_TRY(upload_lex(F, L.lex_fwd.get()));
     } else if (s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS) {
       greedy_coloring(L.A_csc, &L.color, &L.n_colors);
-      // K-Patch form of the pass (patch_rb_kernel) needs colour(row) = parity of (line + column)
-      L.mc_checker = -1;
-      if (L.n_colors == 2 && L.A_rows.patch && L.symmetric) {
+      // K-Patch form of the passes (patch_rb_kernel): the colour of a row is a function of the
+      // parities of its grid line and column
+      L.mc_ctab = -1;
+      if (L.n_colors <= 4 && L.A_rows.patch && L.symmetric && (L.A_rows.patch_m % 2) == 0 &&
+          L.A_rows.patch_m >= 8 && L.n >= 2 * L.A_rows.patch_m) {
         const int64_t m = L.A_rows.patch_m;
-        const int32_t c0 = L.color[0];
+        auto cls = [m](int64_t c) -> int {
+          return c == 0 ? 0 : (c == 1 ? 1 : (c == m - 2 ? 2 : (c == m - 1 ? 3 : 4 + (int)(c & 1))));
+        };
+        int32_t tab[12];
+        const int64_t sample[6] = {0, 1, m - 2, m - 1, 2, 3};
+        for (int p = 0; p < 2; ++p)
+          for (int q = 0; q < 6; ++q) tab[p * 6 + q] = L.color[(size_t)(p * m + sample[q])];
         bool ok = true;
-        for (int64_t i = 0; i < L.n && ok; ++i)
-          ok = L.color[i] == (int32_t)((((i / m) + (i % m)) & 1) ^ c0);
-        if (ok) L.mc_checker = c0;
+        for (int64_t i0 = 0, line = 0; i0 < L.n && ok; i0 += m, ++line) {
+          const int32_t* t = tab + 6 * (line & 1);
+          const int32_t* c = L.color.data() + i0;
+          const int64_t len = std::min<int64_t>(m, L.n - i0);
+          for (int64_t j = 0; j < len; ++j) ok &= c[j] == t[(j < 2 || j >= m - 2) ? cls(j) : 4 + (j & 1)];
+        }
+        if (ok) {
+          L.mc_ctab = 0;
+          for (int q = 0; q < 12; ++q) L.mc_ctab |= tab[q] << (2 * q);
+          if (s->opt.keep_residual && L.n >= s->patch_min_rows) HIP_TRY(L.mc_aux.alloc(sizeof(double) * L.n));
+        }
       }
       ColorPerm CP;
       build_color_perm(L.A_csc, L.color, L.n_colors, &CP);  // column-as-row walk, like SpGS
@@ -2130,6 +2309,7 @@ void amg_hip_set_row_types(int32_t on) { g_row_types = on ? 1 : 0; }
 void amg_hip_set_dict_rows(int32_t rows_per_lane) { set_dict_rows_per_lane(rows_per_lane); }
 void amg_hip_set_patch_tile_flags(int32_t on) { g_patch_tile_flags = on ? 1 : 0; }
 void amg_hip_set_band_chain(int32_t on) { g_no_band_chain = on ? 0 : 1; }
+void amg_hip_set_tail_fusion(int32_t on) { g_tail_fusion = on ? 1 : 0; }
 void amg_hip_set_patch_min_rows(int64_t rows) { g_patch_min_rows = rows < 0 ? INT64_MAX : rows; }
 
 void amg_hip_set_default_layout(int32_t layout) {
@@ -2729,7 +2909,7 @@ amg_hip_status amg_hip_get_vec(amg_hip_solver* s, int32_t level, int32_t which, 
   if (!m || !out) return fail(AMG_HIP_EINVAL, "bad level / vector selector");
   if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "host_only solver has no vectors");
   if (which == 2 && !s->opt.keep_residual &&
-      (fuses_resid_restrict(s, level) || patch_level_ok(s, level) ||
+      (fuses_resid_restrict(s, level) || patch_level_ok(s, level) || mc_patch_ok(s, level) ||
        (level == (int32_t)s->lv.size() - 1 && level > 0)))
     return fail(AMG_HIP_EINVAL, "the residual of this level is not kept (create the solver with "
                                 "opt.keep_residual = 1)");
@@ -2822,10 +3002,12 @@ amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
   const bool slab = patch && s->slab.levels > 0 && s->slab.world > 1;
   for (int i = 0; i < n_launches; ++i) {
     HIP_TRY(hipEventRecord(ev[2 * i], s->stream));
-    if (mc_patch) {  // colours 0, 1 of the pass as patch stages: u -> tmp
+    if (mc_patch) {  // the first launch of the level's down-leg (its colour stages): u -> tmp
+      int nd = 0;
+      const std::vector<McLaunch> plan = mc_plan(s, 0, &nd);
       HIP_TRY(launch_patch_rb(false, false, L.n, L.A_rows.patch_m, L.A_rows.patch_ref(), L.u.as<double>(),
                               L.f.as<double>(), nullptr, s->lv[1].n, L.tmp.as<double>(), nullptr, nullptr,
-                              nullptr, 0, L.mc_checker, s->stream));
+                              nullptr, plan[0].stages, (uint32_t)L.mc_ctab, s->stream));
     } else if (mc) {  // colour 0 of the forward half
       if (L.mc_dict)
         HIP_TRY(launch_dict_gs_color(L.mc_start[0], L.mc_start[1] - L.mc_start[0], L.mc_words, L.mc_wmax,

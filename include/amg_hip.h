@@ -176,6 +176,13 @@ void amg_hip_set_patch_tile_flags(int32_t on);
  * Same bits either way: an A/B switch for tests and tuning.                             */
 void amg_hip_set_band_chain(int32_t on);
 
+/* K-Tail (the deepest levels of the 2+2 true-Jacobi cycle -- at most 4095 rows each --, the
+ * coarsest solve and the way back up in ONE launch of one workgroup) on / off; process-wide, read
+ * when a cycle is enqueued (a captured graph keeps what it was captured with).  Same bits either
+ * way.  OFF by default (AMG_HIP_TAIL_FUSION=1 in the environment turns it on): on MI355X the one
+ * launch takes as long as the launches it replaces.                       */
+void amg_hip_set_tail_fusion(int32_t on);
+
 /* Number of usable HIP devices (0 when none; never fails). */
 int amg_hip_device_count(void);
 

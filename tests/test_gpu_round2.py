@@ -672,3 +672,33 @@ def test_multicolor_patch_form_equals_colour_kernels_2048(amg):
     for a, c in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(a, c)
     assert out[0][3] == out[1][3]
+
+
+@pytest.mark.parametrize("n,L", [(1024, 12), (512, 10), (2048, 13)])
+def test_tail_fusion_is_bit_neutral(amg, oracle, n, L):
+    """K-Tail (round 3, amg_hip_set_tail_fusion(1); off by default -- measured no faster): the
+    deepest levels (<= 4095 rows each), the coarsest solve and the way back up as ONE launch of one
+    workgroup with every vector in LDS, against the same cycle with one launch per step: every
+    level vector bit-equal after 3 cycles; at 512^2 also against the oracle."""
+    kw = dict(smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
+    plain = amg.Multigrid.poisson(n, L, **kw)
+    plain.vcycle(3)           # enqueued (and captured) with the fusion off, the default
+    plain.sync()
+    fused = amg.Multigrid.poisson(n, L, **kw)
+    amg.set_tail_fusion(1)
+    try:
+        fused.vcycle(3)
+        fused.sync()
+    finally:
+        amg.set_tail_fusion(0)
+    for l in range(L):
+        assert np.array_equal(fused.get_soln(l), plain.get_soln(l)), l
+    assert fused.rss() == plain.rss()
+    if n == 512:
+        ref = oracle.Multigrid(oracle.laplacian(n), oracle.rhs(n), L, smoother=oracle.SM_TRUE_JACOBI,
+                               smoother_iters=2, omega=0.6)
+        for _ in range(3):
+            ref.vcycle()
+        assert np.array_equal(fused.get_soln(0), ref.get_vec(0, "u"))
+    fused.close()
+    plain.close()
