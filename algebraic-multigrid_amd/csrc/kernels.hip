@@ -631,8 +631,18 @@ __device__ __forceinline__ void dict_store(const DictStream<WORDS, R>& s, int ro
 // operator re-reads x at +-(half-bandwidth) rows, i.e. a few tiles away, so every XCD
 // gets ONE contiguous run of tiles: the re-reads then hit the L2 that fetched the line
 // (measured on level 1 of the 4096^2 hierarchy: x fetched 2.1x -> see DESIGN.md).
+// on >= 16: a WIDE band (3-D levels: x is re-read a whole grid plane = `on` tiles away, far beyond
+// what an L2 keeps of a contiguous run).  Every XCD then takes the same slab of on / 8 tiles out of
+// EVERY plane, plane after plane: the +-plane re-reads come back after one slab (a few hundred KB)
+// of the XCD's own traffic, the +-line ones sit inside the slab.
 __device__ __forceinline__ int xcd_tile(unsigned b, unsigned nb, int on) {
   if (!on) return (int)b;
+  if (on >= 16) {
+    const unsigned tp = (unsigned)on, s = tp >> 3;
+    if (b >= nb / tp * tp) return (int)b;  // the last, partial plane: plain order
+    const unsigned k = b & 7u, i = b >> 3, p = i / s;
+    return (int)(p * tp + k * s + (i - p * s));
+  }
   const unsigned k = b & 7u, i = b >> 3, q = nb >> 3, r = nb & 7u;
   return (int)(k * q + (k < r ? k : r) + i);
 }
@@ -1850,7 +1860,15 @@ static bool aligned16(const void* a, const void* b, const void* c) {
 // 2+ of the 4096^2 hierarchy: -1..3 us per launch); on the streamed levels beyond the
 // Infinity Cache the plain order is faster (level 0: 91 vs 94 us per sweep, fused
 // residual 108 vs 114 us), although it fetches x 2x at the L2 -- measured per level.
-static int dict_xcd_map(const DictRef& D) { return (g_xcd_map && !D.nt) ? 1 : 0; }
+// tile_rows: rows a workgroup advances by.  A band of >= 16 tiles (the 3-D levels) takes the
+// slab-per-plane order whatever the size of the level (xcd_tile).
+static int g_xcd_slab = 1;
+static int dict_xcd_map(const DictRef& D, int64_t tile_rows = 512) {
+  if (!g_xcd_map) return 0;
+  const int64_t tp = D.hb / tile_rows / 8 * 8;
+  if (g_xcd_slab && tp >= 16 && tp <= (1 << 20)) return (int)tp;
+  return D.nt ? 0 : 1;
+}
 // two rows per lane need 16-byte aligned f / out / codes (vector lane accesses)
 static bool dict_two_rows(int64_t n, const DictRef& D, const void* f, const void* out) {
   return g_dict_rows_per_lane == 2 && n >= 4096 && aligned16(f, out, D.rtype ? nullptr : D.codes) &&
@@ -1870,7 +1888,7 @@ hipError_t launch_dict_resid_restrict(int64_t n, const DictRef& D, const double*
     hipLaunchKernelGGL((dict_resid_restrict_kernel<decltype(W)::value, decltype(U)::value,
                                                    decltype(NTF)::value, decltype(RR)::value>),
                        dim3(tiles), dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff,
-                       D.dval, D.ntab, x, f, r_out, (int)nH, fH, diagH, uH1, uH0, omega, dict_xcd_map(D));
+                       D.dval, D.ntab, x, f, r_out, (int)nH, fH, diagH, uH1, uH0, omega, dict_xcd_map(D, stride));
   });
 }
 hipError_t launch_dict_jacobi_prolong(int64_t n, const DictRef& D, const double* x,
@@ -1887,7 +1905,7 @@ hipError_t launch_dict_jacobi_prolong(int64_t n, const DictRef& D, const double*
     hipLaunchKernelGGL((dict_jacobi_prolong_kernel<decltype(W)::value, decltype(U)::value,
                                                    decltype(NTF)::value, decltype(RR)::value>),
                        dim3(tiles), dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff,
-                       D.dval, D.ntab, x, f, out, omega, (int)n_h, uh_in, uh_out, dict_xcd_map(D));
+                       D.dval, D.ntab, x, f, out, omega, (int)n_h, uh_in, uh_out, dict_xcd_map(D, stride));
   });
 }
 // the two-sweep forms for small levels; see dict_pair_down_kernel / dict_pair_up_kernel
@@ -1941,7 +1959,163 @@ hipError_t launch_dict_pair_up(int64_t n, const DictRef& D, int hb, const double
                        a, f, u_out, omega, hbw, (int)n_h, uh_in, uh_out, dict_xcd_map(D));
   });
 }
-void set_xcd_mapping(int on) { g_xcd_map = on ? 1 : 0; }
+// ---- K-Strip: the multicolour smoother's whole leg of a NARROW level in one launch ----------
+// Below the K-Patch levels (pitch < 128) the symmetric pass of a 4-colour level is 7 colour
+// launches of ~5 us each with almost nothing to do, plus the residual + restriction or the
+// prolongation: 16 launches per level and cycle.  Here a workgroup takes a strip of T consecutive
+// rows plus a halo of (stages [+ 1]) x half-bandwidth rows on either side into LDS (u, f, row
+// types, colours), runs the colour stages LDS -> LDS in place (rows of one colour do not read each
+// other; a barrier between stages), and finishes with the residual + restriction (TAIL) or starts
+// from u + P u_H (PROLONG): the 1-D counterpart of patch_rb_kernel, for any colouring (one colour
+// byte per row).  The halo rows are recomputed by the neighbouring strips with the same
+// expressions; row arithmetic = dict_rows<CSR_GS> / <CSR_RESID> on the level's own dictionary
+// (ascending columns; the colour kernels walk the same entries of the symmetric matrix), transfers
+// = patch_rb_kernel's: same bits as one launch per colour.
+constexpr int STRIP_NT = 512;
+constexpr int STRIP_WMAX = 4608;  // rows of a window (u and f: 2 x 36 KB of LDS)
+typedef StripRef StripArgs;
+int strip_window_max() { return STRIP_WMAX; }
+template <int WORDS, int UN, bool PROLONG, bool TAIL>
+__global__ __launch_bounds__(STRIP_NT) void mc_strip_kernel(StripArgs A) {
+  __shared__ __attribute__((aligned(16))) double uw[STRIP_WMAX];
+  __shared__ __attribute__((aligned(16))) double fw[STRIP_WMAX];
+  __shared__ __attribute__((aligned(16))) uint8_t tyw[STRIP_WMAX];
+  __shared__ __attribute__((aligned(16))) uint8_t cw8[STRIP_WMAX];
+  __shared__ DictEntry tabG[256];
+  __shared__ DictEntry tabR[TAIL ? 256 : 1];
+  __shared__ uint64_t wtab[256 * WORDS];
+  const int tid = (int)threadIdx.x;
+  const int t0 = (int)blockIdx.x * A.T, w0 = t0 - A.H;
+  const int W = A.T + 2 * A.H + 2;
+  const int n = A.n;
+  if (tid < 256) {
+    dict_stage_table<CSR_GS>(tabG, A.doff, A.dval, A.ntab);
+    if (TAIL) dict_stage_table<CSR_RESID>(tabR, A.doff, A.dval, A.ntab);
+    dict_stage_words<WORDS>(wtab, A.rwords);
+  }
+  for (int lw = tid; lw < W; lw += STRIP_NT) {
+    const int r = w0 + lw;
+    const bool live = r >= 0 && r < n;
+    const int row = live ? r : 0;
+    double x0 = live ? A.x[row] : 0.0;
+    if (PROLONG) {  // linear_prolong_add_kernel, same guards and order (patch_load)
+      const int nH = A.nH;
+      const int j = row >> 1;
+      const bool odd = (row & 1) != 0;
+      const bool a_ok = live && !odd && j >= 1 && j - 1 < nH;
+      const bool b_ok = live && j < nH;
+      const double a = A.uH[a_ok ? j - 1 : 0];
+      const double b = A.uH[b_ok ? j : 0];
+      double t = 0.0;
+      t = a_ok ? t + 0.5 * a : t;
+      t = b_ok ? t + (odd ? 1.0 : 0.5) * b : t;
+      x0 = live ? x0 + t : x0;
+    }
+    uw[lw] = x0;
+    fw[lw] = live ? A.f[row] : 0.0;
+    tyw[lw] = live ? A.rtype[row] : (uint8_t)255;
+    cw8[lw] = live ? A.color[row] : (uint8_t)255;
+  }
+  __syncthreads();
+  constexpr int E = TAIL ? 1 : 0;
+  for (int sg = 0; sg < A.nst; ++sg) {
+    const uint32_t c = (uint32_t)(A.stages >> (4 * sg)) & 15u;
+    const int ext = (A.nst - 1 - sg + E) * A.hbw;
+    const int lo = A.H - ext, hi = A.H + A.T + 2 + ext;
+    for (int lw = tid * 2; lw < W; lw += 2 * STRIP_NT) {
+      DictStream<WORDS, 2> s;
+      bool did[2];
+      uint32_t ty = 0;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int l = lw + r;
+        did[r] = l >= lo && l < hi && (uint32_t)cw8[l] == c;
+        s.live[r] = did[r];
+        s.fi[r] = fw[l];
+        s.xi[r] = uw[l];
+        ty |= (did[r] ? (uint32_t)tyw[l] : 255u) << (8 * r);
+      }
+      s.ty = ty;
+      dict_expand<WORDS, 2>(s, wtab);
+      double res[2];
+      dict_rows<CSR_GS, WORDS, UN, 2>(s, lw, tabG, uw, 1.0, 0, res);
+      if (did[0]) uw[lw] = res[0];
+      if (did[1]) uw[lw + 1] = res[1];
+    }
+    __syncthreads();
+  }
+  if (TAIL) {  // r = f - A u on the rows the restriction reads, left in the f window
+    for (int lw = tid * 2; lw < W; lw += 2 * STRIP_NT) {
+      DictStream<WORDS, 2> s;
+      bool inr[2];
+      uint32_t ty = 0;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int l = lw + r;
+        inr[r] = l >= A.H && l < A.H + A.T + 2 && tyw[l] != (uint8_t)255;
+        s.live[r] = inr[r];
+        s.fi[r] = fw[l];
+        s.xi[r] = 0.0;
+        ty |= (inr[r] ? (uint32_t)tyw[l] : 255u) << (8 * r);
+      }
+      s.ty = ty;
+      dict_expand<WORDS, 2>(s, wtab);
+      double res[2];
+      dict_rows<CSR_RESID, WORDS, UN, 2>(s, lw, tabR, uw, 1.0, 0, res);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int l = lw + r;
+        if (l >= A.H && l < A.H + A.T + 2) fw[l] = inr[r] ? res[r] : 0.0;
+      }
+    }
+    __syncthreads();
+  }
+  for (int q = tid; q < A.T; q += STRIP_NT) {
+    const int r = t0 + q;
+    if (r < n) {
+      A.u_out[r] = uw[A.H + q];
+      if (TAIL && A.r_out) A.r_out[r] = fw[A.H + q];
+    }
+  }
+  if (TAIL) {
+    for (int qj = tid; 2 * qj < A.T; qj += STRIP_NT) {
+      const int64_t i = (int64_t)t0 + 2 * qj;  // fine row 2c
+      const int64_t cj = i >> 1;
+      if (i >= (int64_t)n || cj >= A.nH) continue;
+      const double* rs = fw + A.H + 2 * qj;
+      double sum = 0.0;  // dict_restrict_tail / linear_restrict_kernel, same guards and order
+      if (i < n) sum += 0.5 * rs[0];
+      if (i + 1 < n) sum += 1.0 * rs[1];
+      if (i + 2 < n) sum += 0.5 * rs[2];
+      A.fH[cj] = sum;
+      if (A.uH_zero) A.uH_zero[cj] = 0.0;  // multigrid.hpp:278
+    }
+  }
+}
+bool strip_ok(const StripRef& A, const DictRef& D) {
+  return D.rtype && D.rwords && D.doff && D.dval && dict_args_ok(A.n, D.words, D.wmax, D.ntab) && A.n >= 2 &&
+         A.T >= 2 && (A.T & 1) == 0 && A.hbw >= D.hb && A.hbw >= 1 && A.nst >= 1 && A.nst <= 16 &&
+         A.T + 2 * A.H + 2 <= STRIP_WMAX && A.color && A.x && A.f && A.u_out && A.u_out != A.x;
+}
+hipError_t launch_mc_strip(bool prolong, bool tail, StripRef A, const DictRef& D, hipStream_t st) {
+  A.H = (A.nst + (tail ? 1 : 0)) * A.hbw;
+  A.rtype = D.rtype; A.rwords = D.rwords; A.doff = D.doff; A.dval = D.dval; A.ntab = D.ntab;
+  if (!strip_ok(A, D) || (prolong && (tail || !A.uH)) || (tail && !A.fH) || A.nH < 1) return hipErrorInvalidValue;
+  const unsigned tiles = (unsigned)((A.n + A.T - 1) / A.T);
+  return dict_dispatch_wu(D.words, D.wmax, [&](auto W, auto U) {
+#define AMG_STRIP(PRO, TL) \
+  hipLaunchKernelGGL((mc_strip_kernel<decltype(W)::value, decltype(U)::value, PRO, TL>), dim3(tiles), dim3(STRIP_NT), 0, st, A)
+    if (tail) AMG_STRIP(false, true);
+    else if (prolong) AMG_STRIP(true, false);
+    else AMG_STRIP(false, false);
+#undef AMG_STRIP
+  });
+}
+
+void set_xcd_mapping(int on) {
+  g_xcd_map = on ? 1 : 0;
+  g_xcd_slab = on == 1 ? 1 : 0;  // 2: contiguous runs only (the round-2 order), an A/B switch
+}
 void set_dict_rows_per_lane(int r) { g_dict_rows_per_lane = r == 1 ? 1 : 2; }
 template <int MODE>
 static hipError_t launch_dict_mode(int64_t n, const DictRef& D, const double* x, const double* f,
@@ -1952,7 +2126,7 @@ static hipError_t launch_dict_mode(int64_t n, const DictRef& D, const double* x,
     hipLaunchKernelGGL((dict_kernel<MODE, decltype(W)::value, decltype(U)::value,
                                     decltype(NTF)::value, decltype(RR)::value>),
                        dim3(tiles), dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff,
-                       D.dval, D.ntab, x, f, out, omega, (int)dshift, dict_xcd_map(D));
+                       D.dval, D.ntab, x, f, out, omega, (int)dshift, dict_xcd_map(D, 256 * (two ? 2 : 1)));
   });
 }
 // the name rocprofv3 prints for the launch launch_dict(mode, ...) makes

@@ -48,6 +48,7 @@ struct DictRef {  // device pointers of one dictionary-coded matrix
   const int32_t* doff = nullptr;     // pair table: column offset from the diagonal column
   const double* dval = nullptr;      //             value
   int scan_new = 99;                 // most entries of a row on one side beyond +-1 (K-GS-scan)
+  int hb = 0;                        // largest |column offset| (3-D levels: ~ one grid plane): tile order
 };
 void set_xcd_mapping(int on);  // contiguous run of tiles per XCD (default on)
 void set_dict_rows_per_lane(int r);  // 1 or 2 (default), tuning / test switch
@@ -172,6 +173,28 @@ hipError_t launch_patch_rb(bool prolong, bool tail, int64_t n, int64_t m, const 
                            const double* f, const double* uH, int64_t nH, double* u_out, double* r_out,
                            double* fH, double* uH_zero, uint32_t stages, uint32_t ctab, hipStream_t st,
                            int64_t line_lo = 0, int64_t line_hi = -1);
+// K-Strip (kernels.hip): the colour stages of a narrow level's whole leg in one launch over strips
+// of T rows (+ halo), any colouring (colour byte per row, < 16 colours); stages: 4 bits per stage.
+// prolong: the input is x + P uH; tail: followed by the residual (r_out optional), the restriction
+// into fH and the zeroing of uH_zero (optional).  u_out != x.  The dictionary must be row-typed.
+struct StripRef {
+  int n = 0, nH = 0, T = 0, H = 0, hbw = 0, nst = 0, ntab = 0;
+  uint64_t stages = 0;
+  const uint8_t* rtype = nullptr;
+  const uint64_t* rwords = nullptr;
+  const int32_t* doff = nullptr;
+  const double* dval = nullptr;
+  const uint8_t* color = nullptr;
+  const double* x = nullptr;
+  const double* f = nullptr;
+  double* u_out = nullptr;
+  double* r_out = nullptr;
+  const double* uH = nullptr;
+  double* fH = nullptr;
+  double* uH_zero = nullptr;
+};
+int strip_window_max();
+hipError_t launch_mc_strip(bool prolong, bool tail, StripRef A, const DictRef& D, hipStream_t st);
 // uh_out = uh_in + P uH for the linear interpolation pair (16-byte aligned vectors)
 hipError_t launch_linear_prolong_to(int64_t n_h, int64_t n_H, const double* uH,
                                     const double* uh_in, double* uh_out, hipStream_t st);

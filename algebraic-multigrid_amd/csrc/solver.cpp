@@ -294,6 +294,7 @@ struct DevMat {
     D.doff = doff.as<int32_t>();
     D.dval = dval.as<double>();
     D.scan_new = scan_new;
+    D.hb = dict_hb;
     return D;
   }
 };
@@ -787,6 +788,7 @@ struct Level {
   // columns 0, 1, m-2, m-1 and the even / odd columns between them)
   int mc_ctab = -1;
   DevMem mc_aux;  // third vector of the patch colour stages when r is kept (opt.keep_residual)
+  DevMem mc_color8;  // colour of every row as one byte (K-Strip, kernels.hip: mc_strip_kernel)
   int32_t n_colors = 0;
   DevMat mc_mat;
   DevMem mc_rowid;
@@ -1137,6 +1139,45 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
   return fail(AMG_HIP_EINVAL, "unknown smoother kind");
 }
 
+// K-Strip: the whole leg of a narrow multicolour level (below the K-Patch pitch) in one launch
+// over strips of rows.  *T_out: rows per strip -- about n / 256 (one wave of workgroups), within
+// what the LDS window leaves after the halo of (stages + 1) half-bandwidths on either side.
+bool mc_strip_ok(const amg_hip_solver* s, int l, int* T_out = nullptr, int* nst_out = nullptr) {
+  if (l < 0 || l + 1 >= (int)s->lv.size()) return false;
+  const Level& L = s->lv[l];
+  const DevMat& A = L.A_rows;
+  if (!(s->opt.smoother == AMG_HIP_SM_MULTICOLOR_GS && s->opt.smoother_iters >= 1 && !s->opt.no_fusion &&
+        L.symmetric && A.dict && A.dict_typed && A.dict_shift == 0 && L.linear && s->opt.stencil_transfers &&
+        L.mc_color8.p != nullptr && L.n_colors >= 1 && L.n_colors <= 15 && s->lv[l + 1].n >= 1 && L.n >= 2 &&
+        !mc_patch_ok(s, l)))
+    return false;
+  const int nst = 2 * L.n_colors * s->opt.smoother_iters - (2 * s->opt.smoother_iters - 1);  // mc_sequence
+  if (nst < 1 || nst > 16) return false;
+  const int hbw = (A.dict_hb + 1) & ~1;
+  const int64_t T_max = ((int64_t)strip_window_max() - 2 - 2 * (int64_t)(nst + 1) * std::max(hbw, 2)) & ~(int64_t)1;
+  if (T_max < 256) return false;
+  int64_t T = ((L.n + 255) / 256 + 1) & ~(int64_t)1;
+  T = std::min<int64_t>(std::max<int64_t>(T, 256), T_max);
+  if (T_out) *T_out = (int)T;
+  if (nst_out) *nst_out = nst;
+  return true;
+}
+static StripRef mc_strip_ref(amg_hip_solver* s, int l) {
+  Level& L = s->lv[l];
+  StripRef R;
+  int T = 0, nst = 0;
+  (void)mc_strip_ok(s, l, &T, &nst);
+  const std::vector<int> q = mc_sequence(L.n_colors, s->opt.smoother_iters);
+  R.n = (int)L.n;
+  R.nH = (int)s->lv[l + 1].n;
+  R.T = T;
+  R.hbw = std::max((L.A_rows.dict_hb + 1) & ~1, 2);
+  R.nst = (int)q.size();
+  for (size_t i = 0; i < q.size() && i < 16; ++i) R.stages |= (uint64_t)(q[i] & 15) << (4 * i);
+  R.color = L.mc_color8.as<uint8_t>();
+  R.f = L.f.as<double>();
+  return R;
+}
 // one symmetric pass: colours 0..nc-1 then nc-1..0; a colour that directly follows itself is not
 // launched again (mc_sequence: the repeat would store the bits already there).  again: the pass
 // follows another pass of the same smoothing call (its colour 0 directly follows colour 0).
@@ -1270,6 +1311,21 @@ amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
       }
       // each launch: row types + x + f + out; the last also f_H, zeroed u_H (and r when kept)
       s->acct(nd * 25.0 * L.n + 16.0 * C.n + (s->opt.keep_residual ? 8.0 * L.n : 0.0));
+      first_sweep_done = false;
+      continue;
+    }
+    if (mc_strip_ok(s, l)) {  // :268 + :272-282 of a narrow level, one launch: u -> tmp
+      Level& L = s->lv[l];
+      Level& C = s->lv[l + 1];
+      StripRef R = mc_strip_ref(s, l);
+      R.x = L.u.as<double>();
+      R.u_out = L.tmp.as<double>();
+      R.r_out = s->opt.keep_residual ? L.r.as<double>() : nullptr;
+      R.fH = C.f.as<double>();
+      R.uH_zero = C.u.as<double>();
+      HIP_TRY(launch_mc_strip(false, true, R, L.A_rows.dict_ref(), st));
+      // row types + colours + x + f + out; f_H, zeroed u_H (and r when kept)
+      s->acct(26.0 * L.n + 16.0 * C.n + (s->opt.keep_residual ? 8.0 * L.n : 0.0));
       first_sweep_done = false;
       continue;
     }
@@ -1428,6 +1484,15 @@ amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
                                 M.stages, (uint32_t)L.mc_ctab, st));
       }
       s->acct((double)(plan.size() - (size_t)nd) * 25.0 * L.n + 8.0 * C.n);
+      continue;
+    }
+    if (mc_strip_ok(s, l)) {  // :294-296 + :300 of a narrow level, one launch: tmp + P u_H -> u
+      StripRef R = mc_strip_ref(s, l);
+      R.x = L.tmp.as<double>();
+      R.u_out = L.u.as<double>();
+      R.uH = C.u.as<double>();
+      HIP_TRY(launch_mc_strip(true, false, R, L.A_rows.dict_ref(), st));
+      s->acct(26.0 * L.n + 8.0 * C.n);
       continue;
     }
     if (patch_level_ok(s, l)) {  // :294-296 + :300 (both sweeps), one launch
@@ -1757,6 +1822,11 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
           for (int q = 0; q < 12; ++q) L.mc_ctab |= tab[q] << (2 * q);
           if (s->opt.keep_residual && L.n >= s->patch_min_rows) HIP_TRY(L.mc_aux.alloc(sizeof(double) * L.n));
         }
+      }
+      if (L.n_colors <= 15 && !(L.mc_ctab >= 0 && L.n >= s->patch_min_rows)) {  // K-Strip's colour bytes
+        std::vector<uint8_t> c8((size_t)L.n);
+        for (int64_t i = 0; i < L.n; ++i) c8[(size_t)i] = (uint8_t)L.color[(size_t)i];
+        HIP_TRY(upload(L.mc_color8, c8.data(), c8.size()));
       }
       ColorPerm CP;
       build_color_perm(L.A_csc, L.color, L.n_colors, &CP);  // column-as-row walk, like SpGS
@@ -2909,7 +2979,7 @@ amg_hip_status amg_hip_get_vec(amg_hip_solver* s, int32_t level, int32_t which, 
   if (!m || !out) return fail(AMG_HIP_EINVAL, "bad level / vector selector");
   if (s->opt.host_only) return fail(AMG_HIP_EINVAL, "host_only solver has no vectors");
   if (which == 2 && !s->opt.keep_residual &&
-      (fuses_resid_restrict(s, level) || patch_level_ok(s, level) || mc_patch_ok(s, level) ||
+      (fuses_resid_restrict(s, level) || patch_level_ok(s, level) || mc_patch_ok(s, level) || mc_strip_ok(s, level) ||
        (level == (int32_t)s->lv.size() - 1 && level > 0)))
     return fail(AMG_HIP_EINVAL, "the residual of this level is not kept (create the solver with "
                                 "opt.keep_residual = 1)");
