@@ -1375,7 +1375,12 @@ hipError_t debug_set_patch_stamps(unsigned long long* p) {
 #define PATCH_STAMP(k)
 #endif
 template <int UN, int UM, bool FIRST, bool NT>
-__global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
+// (four workgroups per CU = 7 waves per SIMD = 72 registers: measured against 6 and 5 waves again in
+// round 3 -- level-0 down-leg 131-135 us at 7, 138-144 at 6, 142-143 at 5)
+#ifndef AMG_PATCH_WAVES
+#define AMG_PATCH_WAVES 7
+#endif
+__global__ __launch_bounds__(PATCH_NT, AMG_PATCH_WAVES) void patch_down_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
     int nent, int ntypes, const double* x, const double* __restrict__ f, double* u_out, double* r_out, int nH,
@@ -1438,7 +1443,7 @@ __global__ __launch_bounds__(PATCH_NT, 7) void patch_down_kernel(
 }
 
 template <int UN, int UM, bool NT>
-__global__ __launch_bounds__(PATCH_NT, 7) void patch_up_kernel(
+__global__ __launch_bounds__(PATCH_NT, AMG_PATCH_WAVES) void patch_up_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
     int nent, int ntypes, const double* x, const double* __restrict__ f, const double* __restrict__ uH, int nH,
@@ -1524,7 +1529,15 @@ __device__ __forceinline__ void patch_stage_color(const PatchCells& pc, int ntyp
 // colouring itself).  Same row arithmetic as the colour kernels
 // (dict_rows<CSR_GS>): ascending-column sum of the off-diagonal terms, IEEE divide.
 template <int UN, int UM, bool NT, bool PROLONG, bool TAIL>
-__global__ __launch_bounds__(PATCH_NT, 7) void patch_rb_kernel(
+// (Register budget: with the stage loop, the colour bits and the residual stage the kernel does not
+// fit the 72 registers of four workgroups per CU -- 26-118 spilled registers, and the scratch
+// traffic showed as 1.6x the write bytes in the PMC record.  At 96 registers (two workgroups per
+// CU) nothing spills: 8192^2 multicolour 190.9 -> 203.2 V-cycles/s, 4096^2 576.9 -> 607.0; three
+// workgroups / 80 registers: 196.5 / 593.1.  The Jacobi kernels, which fit 72, are fastest at four.)
+#ifndef AMG_RB_WAVES
+#define AMG_RB_WAVES 5
+#endif
+__global__ __launch_bounds__(PATCH_NT, AMG_RB_WAVES) void patch_rb_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi, int nent, int ntypes,
     const double* x, const double* __restrict__ f, const double* __restrict__ uH, int nH, double* u_out,

@@ -35,6 +35,8 @@ def must_move(name, grid, levels):
                 extra = {"down": 16 * nH, "up": 8 * nH, "rb": 0}[m.group(1)]
                 if m.group(1) == "rb" and ", true>" in name:   # the tail form also writes f_H and zeroes u_H
                     extra = 16 * nH
+                elif m.group(1) == "rb" and ", true, false>" in name:   # the prolonging form also reads u_H
+                    extra = 8 * nH
                 return n, 25 * n + extra
     return None, None
 
@@ -52,8 +54,9 @@ def main():
     print("Two separate passes (`--pmc FETCH_SIZE --kernel-trace`, `--pmc WRITE_SIZE --kernel-trace`); reads = 2 x FETCH_SIZE")
     print("(gfx950 counts 128-B requests at 64 B), WRITE_SIZE as reported.  `must move` = what the launch reads and")
     print("writes once in the layout it streams (dictionary sweeps: 25 B per row; K-Patch legs: 25 n + 16 n_H down")
-    print("-- the coarse diagonal is a kernel argument under interior tiles --, 25 n + 8 n_H up), where the rows follow")
-    print("from the grid.\n")
+    print("-- the coarse diagonal is a kernel argument under interior tiles --, 25 n + 8 n_H up; multicolour patch stages")
+    print("patch_rb_kernel<slots, mask, nt, prolong, tail>: 25 n, + 8 n_H prolonging, + 16 n_H with the residual +")
+    print("restriction), where the rows follow from the grid.\n")
     print("| kernel | grid (threads) | calls | reads MB | writes MB | traffic MB | rows | must move MB | traffic / must move |")
     print("|---|---|---|---|---|---|---|---|---|")
     keys = sorted((k for k in f if k in w), key=lambda k: -(2 * sum(f[k]) + sum(w[k])))
