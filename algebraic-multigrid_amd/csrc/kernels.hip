@@ -1376,11 +1376,14 @@ hipError_t debug_set_patch_stamps(unsigned long long* p) {
 #endif
 template <int UN, int UM, bool FIRST, bool NT>
 // (four workgroups per CU = 7 waves per SIMD = 72 registers: measured against 6 and 5 waves again in
-// round 3 -- level-0 down-leg 131-135 us at 7, 138-144 at 6, 142-143 at 5)
+// round 3 -- level-0 down-leg 131-135 us at 7, 138-144 at 6, 142-143 at 5.  The down-legs of the
+// 7- and 9-point levels spill 2-7 registers at 72 and run at 6 waves (80 registers, three
+// workgroups per CU): cycle 1288 / 1290 / 1291 -> 1315 / 1305 / 1308 V-cycles/s in alternating runs;
+// their up-legs, which fit, stay at 7: 1296 / 1298 with both at 6.)
 #ifndef AMG_PATCH_WAVES
 #define AMG_PATCH_WAVES 7
 #endif
-__global__ __launch_bounds__(PATCH_NT, AMG_PATCH_WAVES) void patch_down_kernel(
+__global__ __launch_bounds__(PATCH_NT, (UN == 5 ? AMG_PATCH_WAVES : AMG_PATCH_WAVES - 1)) void patch_down_kernel(
     int n, int m, int px_count, const uint8_t* __restrict__ rtype, const double* __restrict__ ptab,
     const double* __restrict__ utabd, const int32_t* __restrict__ utabi,
     int nent, int ntypes, const double* x, const double* __restrict__ f, double* u_out, double* r_out, int nH,
