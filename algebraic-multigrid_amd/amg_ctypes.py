@@ -184,6 +184,7 @@ _SIGS = {
     "amg_hip_set_index16": (None, [C.c_int32]),
     "amg_hip_set_nontemporal": (None, [C.c_int32]),
     "amg_hip_set_dict_rows": (None, [C.c_int32]),
+    "amg_hip_set_dict_stencil": (None, [C.c_int32]),
     "amg_hip_set_xcd_mapping": (None, [C.c_int32]),
     "amg_hip_set_row_types": (None, [C.c_int32]),
     "amg_hip_dict_probe": (C.c_int, [C.c_int64, C.c_int64, _i32p, _i32p, _f64p, C.c_int64,
@@ -270,6 +271,10 @@ def set_index16(on):
 
 def set_dict_rows(rows_per_lane):
     lib().amg_hip_set_dict_rows(int(rows_per_lane))
+
+
+def set_dict_stencil(on):
+    lib().amg_hip_set_dict_stencil(int(on))
 
 
 def dict_probe(rowptr, col, val, ncols, diag_shift=0):

@@ -38,6 +38,7 @@
 //   graph-capturable kernels over hipIpc-mapped peer memory.
 // =============================================================================
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include <cstdio>
@@ -611,6 +612,87 @@ __device__ __forceinline__ void dict_rows(const DictStream<WORDS, R>& s, int row
     }
   }
 }
+// Wave-uniform STENCIL rows (the interior of a 3-D level: almost every wave).  When all 128 rows of
+// a wave share one row type whose columns are the 7-point pattern {-M, -m, -1, 0, +1, +m, +M} or the
+// 15-point pattern {-M, -m, 0, +m, +M} x {-1, 0, +1} (m, M even), a lane's two consecutive rows need
+// 12 / 20 distinct entries of x that sit in aligned pairs: 7 / 15 load instructions (16-byte pairs
+// plus the two outer singles of a triple) instead of the 16 / 32 eight-byte gathers of dict_rows --
+// the sweeps of these levels are bound by the gathers through the vector L1, not by HBM (traffic
+// 1.01 x must-move at 3.9 / 2.4 TB/s) and not by the decode (a scalar-table path with the same
+// gathers measured no faster).  Values come through scalar loads from a per-type table (utd: per
+// type {off-diagonal value or +0.0 [16], value [16], diagonal}, uti: {offset in rows [16], mask of
+// slots in use, pattern 7 / 15 / 0}), built by the host from the same pairs.  Same products in the
+// same slot order: Jacobi adds (+0.0) x for the diagonal slot exactly as dict_rows does -> same
+// bits.  A mixed wave, or one whose type has no pattern, takes dict_rows (dict_stencil_can).
+// (wave-uniform) does this wave qualify?  (Deciding this per WORKGROUP before the LDS tables are
+// staged, so that a workgroup of stencil waves skips the staging -- 12 KB of loads and LDS stores
+// per 512 rows --, was measured no faster: 512^3 +3.2 % against +5.2 % for this form; the early
+// workgroup-wide vote waits for the row types with nothing else in flight.)
+template <int UN>
+__device__ __forceinline__ bool dict_stencil_can(uint32_t ty, const bool (&live)[2],
+                                                 const int32_t* __restrict__ uti) {
+  constexpr int PAT = UN == 7 ? 7 : 15;
+  const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ty & 0xFFu));
+  const bool ok = ty == (t0 | (t0 << 8)) && live[0] && live[1];
+  if (t0 == 255u || __builtin_amdgcn_ballot_w64(!ok) != 0) return false;
+  return uti[t0 * 18u + 17u] == PAT;
+}
+template <int MODE, int UN>
+__device__ __forceinline__ void dict_rows_stencil(uint32_t ty, const double (&fi)[2],
+                                                  const double (&xi)[2], int row0,
+                                                  const double* __restrict__ utd,
+                                                  const int32_t* __restrict__ uti, const double* x,
+                                                  double omega, double (&res)[2]) {
+  static_assert(MODE == CSR_JACOBI || MODE == CSR_RESID, "fast path of the two hot modes");
+  static_assert(UN == 7 || UN == 16, "7-point rows / 15-point rows");
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  constexpr int PAT = UN == 7 ? 7 : 15;
+  const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ty & 0xFFu));
+  const int32_t* ti = uti + t0 * 18u;
+  const double* td = utd + t0 * 33u + (MODE == CSR_RESID ? 16u : 0u);
+  const double* xr = x + row0;  // row0 is even, x 16-byte aligned, m and M even
+  double xx[2][PAT];
+  if (PAT == 7) {
+    const int g[4] = {0, 1, 5, 6};  // slots of -M, -m, +m, +M
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f64x2 v = *reinterpret_cast<const f64x2*>(xr + ti[g[k]]);
+      xx[0][g[k]] = v.x;
+      xx[1][g[k]] = v.y;
+    }
+    const f64x2 c = *reinterpret_cast<const f64x2*>(xr);
+    const double lo = xr[-1], hi = xr[2];
+    xx[0][2] = lo;  xx[0][3] = c.x; xx[0][4] = c.y;
+    xx[1][2] = c.x; xx[1][3] = c.y; xx[1][4] = hi;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {  // triple k: slots 3k, 3k+1, 3k+2 around the offset of slot 3k+1
+      const double* xc = xr + ti[3 * k + 1];
+      const f64x2 c = *reinterpret_cast<const f64x2*>(xc);
+      const double lo = xc[-1], hi = xc[2];
+      xx[0][3 * k] = lo;  xx[0][3 * k + 1] = c.x; xx[0][3 * k + 2] = c.y;
+      xx[1][3 * k] = c.x; xx[1][3 * k + 1] = c.y; xx[1][3 * k + 2] = hi;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    double acc = (MODE == CSR_RESID) ? fi[r] : 0.0;
+#pragma unroll
+    for (int u = 0; u < PAT; ++u) {
+      const double t = td[u] * xx[r][u];
+      if (MODE == CSR_JACOBI) acc += t;   // td[u] = +0.0 for the diagonal slot (dict_stage_table<CSR_JACOBI>)
+      else acc -= t;                      // every slot of the pattern is in use
+    }
+    if (MODE == CSR_RESID) {
+      res[r] = acc;
+    } else {
+      const double diag = td[32];
+      const bool nod = diag == 0.0;
+      const double q = (fi[r] - acc) / (nod ? 1.0 : diag);  // smoother.hpp:136
+      res[r] = nod ? xi[r] : xi[r] + omega * (q - xi[r]);
+    }
+  }
+}
 template <int WORDS, bool NT, int R>
 __device__ __forceinline__ void dict_store(const DictStream<WORDS, R>& s, int row0,
                                            const double (&res)[R], double* out) {
@@ -653,7 +735,8 @@ __global__ __launch_bounds__(256) void dict_kernel(
     int n, const uint64_t* __restrict__ codes, const uint8_t* __restrict__ rtype,
     const uint64_t* __restrict__ rwords, const int32_t* __restrict__ doff,
     const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
-    double* out, double omega, int dshift, int xcd_map) {
+    double* out, double omega, int dshift, int xcd_map, const double* __restrict__ utd,
+    const int32_t* __restrict__ uti) {
   __shared__ DictEntry tab[256];
   __shared__ uint64_t wtab[256 * WORDS];
   const int row0 = (xcd_tile(blockIdx.x, gridDim.x, xcd_map) * 256 + (int)threadIdx.x) * R;
@@ -662,9 +745,16 @@ __global__ __launch_bounds__(256) void dict_kernel(
   dict_stage_table<MODE>(tab, doff, dval, ntab);
   if (rtype) dict_stage_words<WORDS>(wtab, rwords);
   __syncthreads();
-  if (rtype) dict_expand<WORDS, R>(s, wtab);
   double res[R];
-  dict_rows<MODE, WORDS, UN, R>(s, row0, tab, x, omega, dshift, res);
+  bool fast = false;
+  if constexpr ((MODE == CSR_JACOBI || MODE == CSR_RESID) && R == 2 && (UN == 7 || UN == 16)) {
+    if (utd) fast = dict_stencil_can<UN>(s.ty, s.live, uti);
+    if (fast) dict_rows_stencil<MODE, UN>(s.ty, s.fi, s.xi, row0, utd, uti, x, omega, res);
+  }
+  if (!fast) {
+    if (rtype) dict_expand<WORDS, R>(s, wtab);
+    dict_rows<MODE, WORDS, UN, R>(s, row0, tab, x, omega, dshift, res);
+  }
   dict_store<WORDS, NT, R>(s, row0, res, out);
 }
 
@@ -745,7 +835,8 @@ __global__ __launch_bounds__(256) void dict_resid_restrict_kernel(
     const uint64_t* __restrict__ rwords, const int32_t* __restrict__ doff,
     const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
     double* r_out, int nH, double* __restrict__ fH, const double* __restrict__ diagH,
-    double* __restrict__ uH1, double* __restrict__ uH0, double omega, int xcd_map) {
+    double* __restrict__ uH1, double* __restrict__ uH0, double omega, int xcd_map,
+    const double* __restrict__ utd, const int32_t* __restrict__ uti) {
   __shared__ DictEntry tab[256];
   __shared__ uint64_t wtab[256 * WORDS];
   __shared__ double rs[256 * R];
@@ -756,9 +847,16 @@ __global__ __launch_bounds__(256) void dict_resid_restrict_kernel(
   dict_stage_table<CSR_RESID>(tab, doff, dval, ntab);
   if (rtype) dict_stage_words<WORDS>(wtab, rwords);
   __syncthreads();
-  if (rtype) dict_expand<WORDS, R>(s, wtab);
   double res[R];
-  dict_rows<CSR_RESID, WORDS, UN, R>(s, row0, tab, x, omega, 0, res);
+  bool fast = false;
+  if constexpr (R == 2 && (UN == 7 || UN == 16)) {
+    if (utd) fast = dict_stencil_can<UN>(s.ty, s.live, uti);
+    if (fast) dict_rows_stencil<CSR_RESID, UN>(s.ty, s.fi, s.xi, row0, utd, uti, x, omega, res);
+  }
+  if (!fast) {
+    if (rtype) dict_expand<WORDS, R>(s, wtab);
+    dict_rows<CSR_RESID, WORDS, UN, R>(s, row0, tab, x, omega, 0, res);
+  }
   if (r_out) dict_store<WORDS, NT, R>(s, row0, res, r_out);  // nullptr: r is dead after this kernel
 #pragma unroll
   for (int r = 0; r < R; ++r) rs[threadIdx.x * R + r] = s.live[r] ? res[r] : 0.0;
@@ -773,7 +871,8 @@ __global__ __launch_bounds__(256) void dict_jacobi_prolong_kernel(
     int n, const uint64_t* __restrict__ codes, const uint8_t* __restrict__ rtype,
     const uint64_t* __restrict__ rwords, const int32_t* __restrict__ doff,
     const double* __restrict__ dval, int ntab, const double* x, const double* __restrict__ f,
-    double* out, double omega, int n_h, const double* uh_in, double* uh_out, int xcd_map) {
+    double* out, double omega, int n_h, const double* uh_in, double* uh_out, int xcd_map,
+    const double* __restrict__ utd, const int32_t* __restrict__ uti) {
   __shared__ DictEntry tab[256];
   __shared__ uint64_t wtab[256 * WORDS];
   __shared__ double rs[256 * R];
@@ -785,9 +884,16 @@ __global__ __launch_bounds__(256) void dict_jacobi_prolong_kernel(
   dict_stage_table<CSR_JACOBI>(tab, doff, dval, ntab);
   if (rtype) dict_stage_words<WORDS>(wtab, rwords);
   __syncthreads();
-  if (rtype) dict_expand<WORDS, R>(s, wtab);
   double res[R];
-  dict_rows<CSR_JACOBI, WORDS, UN, R>(s, row0, tab, x, omega, 0, res);
+  bool fast = false;
+  if constexpr (R == 2 && (UN == 7 || UN == 16)) {
+    if (utd) fast = dict_stencil_can<UN>(s.ty, s.live, uti);
+    if (fast) dict_rows_stencil<CSR_JACOBI, UN>(s.ty, s.fi, s.xi, row0, utd, uti, x, omega, res);
+  }
+  if (!fast) {
+    if (rtype) dict_expand<WORDS, R>(s, wtab);
+    dict_rows<CSR_JACOBI, WORDS, UN, R>(s, row0, tab, x, omega, 0, res);
+  }
   dict_store<WORDS, NT, R>(s, row0, res, out);
 #pragma unroll
   for (int r = 0; r < R; ++r) rs[threadIdx.x * R + r] = s.live[r] ? res[r] : 0.0;
@@ -1879,6 +1985,14 @@ static bool aligned16(const void* a, const void* b, const void* c) {
 // tile_rows: rows a workgroup advances by.  A band of >= 16 tiles (the 3-D levels) takes the
 // slab-per-plane order whatever the size of the level (xcd_tile).
 static int g_xcd_slab = 1;
+// paired-load path of wave-uniform 7- / 15-point rows (set_dict_stencil / AMG_HIP_DICT_STENCIL=0: A/B switch)
+static int g_dict_stencil = [] {
+  const char* e = std::getenv("AMG_HIP_DICT_STENCIL");
+  return (e && *e == '0') ? 0 : 1;
+}();
+static const double* dict_stencil_tab(const DictRef& D, const double* x) {
+  return (g_dict_stencil && D.utd && D.uti && D.rtype && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? D.utd : nullptr;
+}
 static int dict_xcd_map(const DictRef& D, int64_t tile_rows = 512) {
   if (!g_xcd_map) return 0;
   const int64_t tp = D.hb / tile_rows / 8 * 8;
@@ -1904,7 +2018,8 @@ hipError_t launch_dict_resid_restrict(int64_t n, const DictRef& D, const double*
     hipLaunchKernelGGL((dict_resid_restrict_kernel<decltype(W)::value, decltype(U)::value,
                                                    decltype(NTF)::value, decltype(RR)::value>),
                        dim3(tiles), dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff,
-                       D.dval, D.ntab, x, f, r_out, (int)nH, fH, diagH, uH1, uH0, omega, dict_xcd_map(D, stride));
+                       D.dval, D.ntab, x, f, r_out, (int)nH, fH, diagH, uH1, uH0, omega, dict_xcd_map(D, stride),
+                       dict_stencil_tab(D, x), D.uti);
   });
 }
 hipError_t launch_dict_jacobi_prolong(int64_t n, const DictRef& D, const double* x,
@@ -1921,7 +2036,8 @@ hipError_t launch_dict_jacobi_prolong(int64_t n, const DictRef& D, const double*
     hipLaunchKernelGGL((dict_jacobi_prolong_kernel<decltype(W)::value, decltype(U)::value,
                                                    decltype(NTF)::value, decltype(RR)::value>),
                        dim3(tiles), dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff,
-                       D.dval, D.ntab, x, f, out, omega, (int)n_h, uh_in, uh_out, dict_xcd_map(D, stride));
+                       D.dval, D.ntab, x, f, out, omega, (int)n_h, uh_in, uh_out, dict_xcd_map(D, stride),
+                       dict_stencil_tab(D, x), D.uti);
   });
 }
 // the two-sweep forms for small levels; see dict_pair_down_kernel / dict_pair_up_kernel
@@ -2133,6 +2249,7 @@ void set_xcd_mapping(int on) {
   g_xcd_slab = on == 1 ? 1 : 0;  // 2: contiguous runs only (the round-2 order), an A/B switch
 }
 void set_dict_rows_per_lane(int r) { g_dict_rows_per_lane = r == 1 ? 1 : 2; }
+void set_dict_stencil(int on) { g_dict_stencil = on ? 1 : 0; }
 template <int MODE>
 static hipError_t launch_dict_mode(int64_t n, const DictRef& D, const double* x, const double* f,
                                    double* out, double omega, int64_t dshift, hipStream_t st) {
@@ -2142,7 +2259,8 @@ static hipError_t launch_dict_mode(int64_t n, const DictRef& D, const double* x,
     hipLaunchKernelGGL((dict_kernel<MODE, decltype(W)::value, decltype(U)::value,
                                     decltype(NTF)::value, decltype(RR)::value>),
                        dim3(tiles), dim3(256), 0, st, (int)n, D.codes, D.rtype, D.rwords, D.doff,
-                       D.dval, D.ntab, x, f, out, omega, (int)dshift, dict_xcd_map(D, 256 * (two ? 2 : 1)));
+                       D.dval, D.ntab, x, f, out, omega, (int)dshift, dict_xcd_map(D, 256 * (two ? 2 : 1)),
+                       dshift == 0 ? dict_stencil_tab(D, x) : nullptr, D.uti);
   });
 }
 // the name rocprofv3 prints for the launch launch_dict(mode, ...) makes

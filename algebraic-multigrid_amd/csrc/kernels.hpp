@@ -49,9 +49,15 @@ struct DictRef {  // device pointers of one dictionary-coded matrix
   const double* dval = nullptr;      //             value
   int scan_new = 99;                 // most entries of a row on one side beyond +-1 (K-GS-scan)
   int hb = 0;                        // largest |column offset| (3-D levels: ~ one grid plane): tile order
+  // per row type, for waves whose rows all share one 7- / 15-point stencil type (scalar loads): utd =
+  // {off-diagonal value or +0.0 [16], value [16], diagonal}, uti = {offset in rows [16], mask of
+  // slots in use, pattern 7 / 15 / 0}; null: none
+  const double* utd = nullptr;
+  const int32_t* uti = nullptr;
 };
 void set_xcd_mapping(int on);  // contiguous run of tiles per XCD (default on)
 void set_dict_rows_per_lane(int r);  // 1 or 2 (default), tuning / test switch
+void set_dict_stencil(int on);       // paired-load path for wave-uniform 7- / 15-point rows (default on)
 hipError_t launch_dict(int mode, int64_t n, const DictRef& D, const double* x, const double* f,
                        double* out, double omega, int64_t diag_shift, hipStream_t st);
 void dict_kernel_name(int mode, int64_t n, const DictRef& D, const void* f, const void* out,

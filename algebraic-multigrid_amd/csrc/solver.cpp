@@ -257,6 +257,7 @@ struct DevMat {
   int dict_hb = 0;            // largest |column offset| of the table (half-bandwidth in rows)
   bool dict_typed = false;    // second level: one byte per row into a table of code words
   DevMem dcodes, doff, dval, drtype, drwords;
+  DevMem dutd, duti;  // per row type: values / diagonal, offsets + slot mask + stencil pattern (DictRef::utd, uti)
   // K-GS-scan: nearest dependency of a lexicographic sweep other than the chained neighbour
   // (min |offset| over the pairs with |offset| >= 2) and the farthest one; 0 = not usable
   int64_t scan_gap = 0, scan_far = 0;
@@ -295,6 +296,8 @@ struct DevMat {
     D.dval = dval.as<double>();
     D.scan_new = scan_new;
     D.hb = dict_hb;
+    D.utd = (dict_typed && dutd.p) ? dutd.as<double>() : nullptr;
+    D.uti = (dict_typed && duti.p) ? duti.as<int32_t>() : nullptr;
     return D;
   }
 };
@@ -401,6 +404,56 @@ hipError_t finish_dict(const DictMat& T, int64_t n, int64_t diag_shift, DevMat* 
     if ((e = upload(D->drwords, T.rwords.data(), T.rwords.size())) != hipSuccess) return e;
   if ((e = upload(D->doff, T.doff.data(), T.doff.size())) != hipSuccess) return e;
   if ((e = upload(D->dval, T.dval.data(), T.dval.size())) != hipSuccess) return e;
+  if (D->dict_typed && diag_shift == 0 && T.rwords.size() >= (size_t)256 * T.words && T.words <= 2) {
+    // The pairs of every row type laid out per slot, and whether its columns form the 7-point
+    // pattern {-M, -m, -1, 0, 1, m, M} or the 15-point pattern {-M, -m, 0, m, M} x {-1, 0, 1} with
+    // even m < M (kernels.hip: dict_rows_stencil): same values, same slot order as the LDS tables.
+    std::vector<double> ud((size_t)256 * 33, 0.0);
+    std::vector<int32_t> ui((size_t)256 * 18, 0);
+    bool any = false;
+    for (int t = 0; t < 255; ++t) {
+      double diag = 0.0;
+      int32_t mask = 0;
+      int cnt = 0;
+      int64_t o[16];
+      bool dense = true;  // the slots in use are 0 .. cnt-1
+      for (int sl = 0; sl < 8 * T.words; ++sl) {
+        const int code = (int)((T.rwords[(size_t)t * T.words + sl / 8] >> (8 * (sl % 8))) & 0xFF);
+        if (code == 0xFF || code >= (int)T.doff.size()) continue;
+        const int32_t off = T.doff[(size_t)code];
+        const double v = T.dval[(size_t)code];
+        dense = dense && sl == cnt;
+        o[cnt++] = off;
+        ui[(size_t)t * 18 + sl] = off;
+        ud[(size_t)t * 33 + 16 + sl] = v;
+        ud[(size_t)t * 33 + sl] = off == 0 ? 0.0 : v;
+        if (off == 0) diag = diag + v;
+        mask |= (int32_t)1 << sl;
+      }
+      ud[(size_t)t * 33 + 32] = diag;
+      ui[(size_t)t * 18 + 16] = mask;
+      int pat = 0;
+      if (dense && cnt == 7) {
+        const int64_t m = o[5], M = o[6];
+        if (o[0] == -M && o[1] == -m && o[2] == -1 && o[3] == 0 && o[4] == 1 && m > 1 && M > m && m % 2 == 0 &&
+            M % 2 == 0)
+          pat = 7;
+      } else if (dense && cnt == 15) {
+        const int64_t m = o[10], M = o[13];
+        bool okp = m > 2 && M > m + 2 && m % 2 == 0 && M % 2 == 0;
+        const int64_t c[5] = {-M, -m, 0, m, M};
+        for (int k = 0; k < 5 && okp; ++k)
+          okp = o[3 * k] == c[k] - 1 && o[3 * k + 1] == c[k] && o[3 * k + 2] == c[k] + 1;
+        if (okp) pat = 15;
+      }
+      ui[(size_t)t * 18 + 17] = pat;
+      any = any || pat != 0;
+    }
+    if (any) {
+      if ((e = upload(D->dutd, ud.data(), ud.size())) != hipSuccess) return e;
+      if ((e = upload(D->duti, ui.data(), ui.size())) != hipSuccess) return e;
+    }
+  }
   D->scan_gap = D->scan_far = 0;
   if (diag_shift == 0) {
     int64_t gap = INT64_MAX, far = 1;
@@ -2377,6 +2430,7 @@ void amg_hip_set_nontemporal(int32_t on) { g_nontemporal = on ? 1 : 0; }
 void amg_hip_set_xcd_mapping(int32_t on) { set_xcd_mapping(on); }
 void amg_hip_set_row_types(int32_t on) { g_row_types = on ? 1 : 0; }
 void amg_hip_set_dict_rows(int32_t rows_per_lane) { set_dict_rows_per_lane(rows_per_lane); }
+void amg_hip_set_dict_stencil(int32_t on) { set_dict_stencil(on); }
 void amg_hip_set_patch_tile_flags(int32_t on) { g_patch_tile_flags = on ? 1 : 0; }
 void amg_hip_set_band_chain(int32_t on) { g_no_band_chain = on ? 0 : 1; }
 void amg_hip_set_tail_fusion(int32_t on) { g_tail_fusion = on ? 1 : 0; }

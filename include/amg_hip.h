@@ -153,7 +153,9 @@ void amg_hip_set_index16(int32_t on);
  * on): the once-read matrix then does not evict the x lines the gathers re-use.  */
 void amg_hip_set_nontemporal(int32_t on);
 /* K-Dict: give every XCD one contiguous run of row tiles, so that the +-bandwidth
- * re-reads of x hit the L2 that fetched them (default on).  Tuning switch.       */
+ * re-reads of x hit the L2 that fetched them; on wide bands (3-D levels) the same slab of lines of
+ * every grid plane instead (default on = 1; 2 = contiguous runs everywhere, the round-2 order;
+ * 0 = plain order).  Tuning switch.                                                */
 void amg_hip_set_xcd_mapping(int32_t on);
 /* K-Dict second level: when a dictionary-coded matrix has at most 255 distinct rows, store
  * one byte per row into a table of code words instead of the code words themselves
@@ -163,6 +165,12 @@ void amg_hip_set_row_types(int32_t on);
 /* K-Dict rows per lane: 2 (default; 16-byte lane accesses) or 1.  Process-wide;
  * bit-identical results, a tuning / test switch.                                */
 void amg_hip_set_dict_rows(int32_t rows_per_lane);
+/* K-Dict: waves whose 128 rows all share one 7-point ({-M,-m,-1,0,1,m,M}) or 15-point
+ * ({-M,-m,0,m,M} x {-1,0,1}) row type -- the interior of a 3-D level -- fetch x as aligned pairs
+ * (7 / 15 loads per lane instead of 16 / 32 gathers) with the values from a per-type scalar table.
+ * Process-wide, default on (AMG_HIP_DICT_STENCIL=0 in the environment turns it off);
+ * bit-identical results, a tuning / test switch.                                                */
+void amg_hip_set_dict_stencil(int32_t on);
 /* K-Patch (temporal blocking of the 2+2 true-Jacobi cycle: a level's down-leg and up-leg in
  * one launch each over 2-D patches of the level) is used on levels of at least this many rows
  * (default 10^6; negative = never).  Process-wide, read when a solver is created: existing

@@ -94,3 +94,28 @@ def test_multicolor_default_threshold_uses_patch_stages_below_level_0(amg):
         assert np.array_equal(a, c)
     assert res[0][3] == res[1][3]
     assert res[0][4] < 0.8 * res[1][4]
+
+
+def test_3d_stencil_rows_paired_loads_are_bit_neutral(amg):
+    """3-D 7-point 160^3 / 13 levels (4.1 M rows; lines of 160, so most waves of 128 rows lie inside
+    one line and share the interior row type): the paired-load path of wave-uniform 7- / 15-point
+    rows (dict_rows_stencil) and the slab-per-plane tile order against plain dict_rows in the
+    round-2 tile order -- every level vector bitwise after 3 cycles, same rss."""
+    n, L = 160, 13
+    out = []
+    for on in (1, 0):
+        amg.set_dict_stencil(on)
+        amg.set_xcd_mapping(1 if on else 2)
+        try:
+            mg = amg.Multigrid.poisson(n, L, dim=3, smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
+            mg.vcycle(3)
+            out.append(([mg.get_soln(l) for l in range(L)], [mg.get_rhs(l) for l in range(1, L)], mg.rss()))
+            mg.close()
+        finally:
+            amg.set_dict_stencil(1)
+            amg.set_xcd_mapping(1)
+    for l in range(L):
+        assert np.array_equal(out[0][0][l], out[1][0][l]), l
+    for l in range(L - 1):
+        assert np.array_equal(out[0][1][l], out[1][1][l]), l + 1
+    assert out[0][2] == out[1][2]
