@@ -325,7 +325,7 @@ def main():
                     help="window sharding: number of distributed levels (-1 = every level of at least "
                          "--window-min-rows rows whose halo overhead stays below 35 %% of a block)")
     ap.add_argument("--window-min-rows", type=int, default=500000)
-    ap.add_argument("--comm", choices=["safe", "auto", "p2p", "slab", "window", "ipc", "graph"], default="safe",
+    ap.add_argument("--comm", choices=["safe", "auto", "p2p", "slab", "window", "library", "ipc", "graph"], default="safe",
                     help="multi-GPU halo exchange.  safe (default) = the configurations built on "
                          "plain RCCL calls only: replicated (nothing distributed: timed first, it is "
                          "the reference every other one must reproduce), p2p (a send/recv before every "
@@ -333,7 +333,9 @@ def main():
                          "lines + redundant halo: one grouped send/recv and one all-gather per cycle) and "
                          "window (every rank sets up and stores only its window of the distributed levels; "
                          "the only sharded form of --smoother multicolor and --dim 3); "
-                         "the fastest one is reported.  auto = additionally "
+                         "the fastest one is reported.  library = safe + the slab / window cycles as ONE "
+                         "C call each over the library's own RCCL communicator (amg_hip_slab_cycle, "
+                         "amg_hip_window_cycle; run with a world of 1 only so far).  auto = additionally "
                          "ipc (hipIpc pushes + stream memory ops) and graph (pushes + flags as "
                          "kernels, one hipGraph per rank): experimental, never run on real xGMI "
                          "links; bounded by a watchdog that exits with status 3 when one hangs.  "

@@ -70,4 +70,4 @@ def test_multi_gpu_default_is_the_safe_transport_set():
     finally:
         sys.argv = argv
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert 'choices=["safe", "auto", "p2p", "slab", "window", "ipc", "graph"], default="safe"' in src
+    assert 'choices=["safe", "auto", "p2p", "slab", "window", "library", "ipc", "graph"], default="safe"' in src
