@@ -3498,11 +3498,15 @@ __device__ __forceinline__ void band_chain_stage(const double* __restrict__ src,
 template <int W>
 __global__ __launch_bounds__(64) void band_chain_kernel(
     int n, const double* __restrict__ cf, const double* __restrict__ cb,
-    const double* __restrict__ dg, const double* __restrict__ f, double* __restrict__ x) {
+    const double* __restrict__ dg, const double* __restrict__ f, double* __restrict__ x, int n_h,
+    const double* uh_in, double* uh_out, int pre) {
   extern __shared__ double chain_lds[];
   const int np = band_chain_pad(n);
-  double* ops = chain_lds;           // np x W
+  double* ops = chain_lds;           // np x W: forward operands
   double* v = chain_lds + np * W;    // np: right-hand side in step order, then the result
+  // backward operands: staged with the forward ones when the LDS allows (pre: no global round
+  // trip between the two passes), else over them after the first pass
+  double* opb = pre ? v + np : ops;
   const int lane = threadIdx.x;
   double dgv[32];                    // the diagonal, mirrored, requested before the first pass
 #pragma unroll
@@ -3510,8 +3514,21 @@ __global__ __launch_bounds__(64) void band_chain_kernel(
     const int s = lane + 64 * q;
     dgv[q] = s < n ? dg[n - 1 - s] : 1.0;
   }
+  // the fine vector the result is prolonged into: its first 1024 rows are requested now, the solve
+  // hides the round trip
+  double a0[8], a1[8];
+  auto fetch_fine = [&](int j0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = 2 * (j0 + q * 64 + lane);
+      a0[q] = i < n_h ? uh_in[i] : 0.0;
+      a1[q] = i + 1 < n_h ? uh_in[i + 1] : 0.0;
+    }
+  };
+  if (uh_out) fetch_fine(0);
   band_chain_stage(cf, ops, n * W, np * W, lane);
   band_chain_stage(f, v, n, np, lane);
+  if (pre) band_chain_stage(cb, opb, n * W, np * W, lane);
   lds_barrier();
   band_chain_pass<W>(n, ops, v);                 // L y = f
   lds_barrier();
@@ -3521,7 +3538,7 @@ __global__ __launch_bounds__(64) void band_chain_kernel(
     const int s = lane + 64 * q;
     z[q] = s < n ? v[n - 1 - s] / dgv[q] : 0.0;
   }
-  band_chain_stage(cb, ops, n * W, n * W, lane);
+  if (!pre) band_chain_stage(cb, opb, n * W, n * W, lane);
   lds_barrier();
 #pragma unroll
   for (int q = 0; q < 32; ++q) {
@@ -3529,19 +3546,45 @@ __global__ __launch_bounds__(64) void band_chain_kernel(
     if (s < n) v[s] = z[q];
   }
   lds_barrier();
-  band_chain_pass<W>(n, ops, v);                 // L^T x = z, step s = row n-1-s
+  band_chain_pass<W>(n, opb, v);                 // L^T x = z, step s = row n-1-s
   lds_barrier();
   for (int s = lane; s < n; s += 64) x[n - 1 - s] = v[s];
+  if (uh_out) {
+    // the prolongation into the level above (multigrid.hpp:294-296 for l = L-2), which would
+    // otherwise be a launch of its own: uh_out = uh_in + P x, linear_prolong_add2_kernel's
+    // expressions and order; x sits in v[] mirrored (x_j = v[n-1-j])
+    // (the loads of eight pairs issued together: one global round trip per 1024 fine rows)
+    for (int j0 = 0; 2 * j0 < n_h; j0 += 64 * 8) {
+      if (j0 > 0) fetch_fine(j0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = j0 + q * 64 + lane, i = 2 * j;
+        if (i >= n_h) continue;
+        double t0 = 0.0, t1 = 0.0;
+        const double b = (j < n) ? v[n - 1 - j] : 0.0;
+        if (j >= 1 && j - 1 < n) t0 += 0.5 * v[n - j];
+        if (j < n) {
+          t0 += 0.5 * b;
+          t1 += 1.0 * b;
+        }
+        uh_out[i] = a0[q] + t0;
+        if (i + 1 < n_h) uh_out[i + 1] = a1[q] + t1;
+      }
+    }
+  }
 }
 bool band_chain_ok(int64_t n, int64_t w) { return w >= 1 && w <= 3 && n >= 1 && n <= 2048; }
 hipError_t launch_band_chain(int64_t n, int w, const double* cf, const double* cb, const double* dg,
-                             const double* f, double* x, hipStream_t st) {
-  if (!band_chain_ok(n, w)) return hipErrorInvalidValue;
-  const size_t lds = sizeof(double) * (size_t)band_chain_pad((int)n) * (size_t)(w + 1);
+                             const double* f, double* x, hipStream_t st, int64_t n_h, const double* uh_in,
+                             double* uh_out) {
+  if (!band_chain_ok(n, w) || (uh_out && (!uh_in || n_h < 1 || n_h > 2 * n + 2))) return hipErrorInvalidValue;
+  const size_t np = (size_t)band_chain_pad((int)n);
+  const int pre = sizeof(double) * np * (size_t)(2 * w + 1) <= (size_t)48 * 1024 ? 1 : 0;
+  const size_t lds = sizeof(double) * np * (size_t)(pre ? 2 * w + 1 : w + 1);
   switch (w) {
-    case 1: hipLaunchKernelGGL(band_chain_kernel<1>, dim3(1), dim3(64), lds, st, (int)n, cf, cb, dg, f, x); break;
-    case 2: hipLaunchKernelGGL(band_chain_kernel<2>, dim3(1), dim3(64), lds, st, (int)n, cf, cb, dg, f, x); break;
-    default: hipLaunchKernelGGL(band_chain_kernel<3>, dim3(1), dim3(64), lds, st, (int)n, cf, cb, dg, f, x); break;
+    case 1: hipLaunchKernelGGL(band_chain_kernel<1>, dim3(1), dim3(64), lds, st, (int)n, cf, cb, dg, f, x, (int)n_h, uh_in, uh_out, pre); break;
+    case 2: hipLaunchKernelGGL(band_chain_kernel<2>, dim3(1), dim3(64), lds, st, (int)n, cf, cb, dg, f, x, (int)n_h, uh_in, uh_out, pre); break;
+    default: hipLaunchKernelGGL(band_chain_kernel<3>, dim3(1), dim3(64), lds, st, (int)n, cf, cb, dg, f, x, (int)n_h, uh_in, uh_out, pre); break;
   }
   return hipGetLastError();
 }

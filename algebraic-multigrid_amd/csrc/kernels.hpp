@@ -298,7 +298,8 @@ hipError_t launch_band_solve(int64_t n, int m, const double* sched_f, const doub
 // cf / cb: n x w operands per step (host_setup.hpp: band_chain_schedule)
 bool band_chain_ok(int64_t n, int64_t w);
 hipError_t launch_band_chain(int64_t n, int w, const double* cf, const double* cb, const double* dg,
-                             const double* f, double* x, hipStream_t st);
+                             const double* f, double* x, hipStream_t st, int64_t n_h = 0,
+                             const double* uh_in = nullptr, double* uh_out = nullptr);
 // Any half-bandwidth (K-BandWide): rows in blocks of 64; sched_f/sched_b hold per block a
 // [w][64] panel of the operands that reach into earlier blocks followed by the block's own
 // [64][64] triangle (host_setup: band_wide_schedule).  w + 64 <= 8192 (LDS ring).

@@ -738,8 +738,10 @@ amg_hip_status upload_coarse(const Sparse& A, int want_fast, CoarseOnDev* C) {
   return AMG_HIP_OK;
 }
 // x = A^-1 f; y: scratch of n doubles (BAND / WIDE)
+// uh_out (K-BandChain only): also uh_out = uh_in + P x, the prolongation into the level above
 hipError_t launch_coarse(const CoarseOnDev& C, const double* f, double* y, double* x,
-                         hipStream_t st) {
+                         hipStream_t st, int64_t n_h = 0, const double* uh_in = nullptr,
+                         double* uh_out = nullptr) {
   switch (C.kind) {
     case COARSE_SPIKE: {
       SpikeArgs a = C.spike->a;
@@ -752,7 +754,7 @@ hipError_t launch_coarse(const CoarseOnDev& C, const double* f, double* y, doubl
                               y, x, st);
     case COARSE_CHAIN:
       return launch_band_chain(C.n, (int)C.w, C.sf.as<double>(), C.sb.as<double>(), C.d.as<double>(),
-                               f, x, st);
+                               f, x, st, n_h, uh_in, uh_out);
     default:
       return launch_band_solve(C.n, C.m, C.sf.as<double>(), C.sb.as<double>(), C.d.as<double>(),
                                f, y, x, st);
@@ -1505,21 +1507,35 @@ amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
       }
     }
   }
-  if (!ranged && !tail_done) {                                     // :287-288
-    RoctxRange range("coarse solve", -1);
-    if (s->opt.window)
-      return fail(AMG_HIP_EINVAL, "a window solver (opt.window) runs by parts: amg_hip_window_run");
-    Level& C = s->lv[nl - 1];
-    HIP_TRY(launch_coarse(s->coarse, C.f.as<double>(), C.tmp.as<double>(), C.u.as<double>(), st));
-    // banded L D L^T solve: the band of L forwards and backwards, D, f, u
-    s->acct(16.0 * (double)C.n * (double)std::max<int64_t>(s->coarse.w, 1) + 24.0 * C.n);
-  }
   // where the prolongation INTO level l lands: a level whose two post-sweeps run as one
   // launch reads u + P u_{l+1} from tmp (its second sweep then writes u; no in-place race
   // between the tiles), every other level takes it in place
   auto up_target = [&](int l) -> double* {
     return pair_up_ok(s, l) ? s->lv[l].tmp.as<double>() : s->lv[l].u.as<double>();
   };
+  int prolonged_by_solve = -1;  // level whose :294-296 the coarsest solve's launch did (K-BandChain)
+  if (!ranged && !tail_done) {                                     // :287-288
+    RoctxRange range("coarse solve", -1);
+    if (s->opt.window)
+      return fail(AMG_HIP_EINVAL, "a window solver (opt.window) runs by parts: amg_hip_window_run");
+    Level& C = s->lv[nl - 1];
+    const int lp = nl - 2;  // plain stencil prolongation into level L-2: one launch less when fused
+    const bool fuse_p = lp >= 0 && s->coarse.kind == COARSE_CHAIN && !s->opt.no_fusion && s->lv[lp].linear &&
+                        s->opt.stencil_transfers && !mc_patch_ok(s, lp) && !mc_strip_ok(s, lp) &&
+                        !patch_level_ok(s, lp) && !jacobi_fuses_prolong(s, lp) && !fuses_jacobi_prolong(s, lp) &&
+                        (part == CYCLE_ALL || (part == CYCLE_SLAB_TAIL && lp >= k));
+    if (fuse_p) {
+      Level& Lp = s->lv[lp];
+      HIP_TRY(launch_coarse(s->coarse, C.f.as<double>(), C.tmp.as<double>(), C.u.as<double>(), st, Lp.n,
+                            Lp.u.as<double>(), up_target(lp)));
+      s->acct(16.0 * Lp.n);
+      prolonged_by_solve = lp;
+    } else {
+      HIP_TRY(launch_coarse(s->coarse, C.f.as<double>(), C.tmp.as<double>(), C.u.as<double>(), st));
+    }
+    // banded L D L^T solve: the band of L forwards and backwards, D, f, u
+    s->acct(16.0 * (double)C.n * (double)std::max<int64_t>(s->coarse.w, 1) + 24.0 * C.n);
+  }
   const int up_from = part == CYCLE_SLAB_UP ? k - 1 : (part == CYCLE_SLAB_DOWN ? -1 : (tail_done ? tail_lt - 1 : nl - 2));
   const int up_to = part == CYCLE_SLAB_TAIL ? k : 0;
   for (int l = up_from; l >= up_to; --l) {                         // :291
@@ -1576,6 +1592,8 @@ amg_hip_status enqueue_vcycle_body(amg_hip_solver* s, int part) {
     }
     if (fuses_jacobi_prolong(s, l)) {
       // :294-296 was done by the last sweep of level l+1
+    } else if (l == prolonged_by_solve) {
+      // :294-296 was done by the launch of the coarsest solve
     } else if (L.linear && s->opt.stencil_transfers) {             // :294-296
       if (up_target(l) != L.u.as<double>())
         HIP_TRY(launch_linear_prolong_to(L.n, C.n, C.u.as<double>(), L.u.as<double>(), up_target(l), st));
