@@ -2623,6 +2623,11 @@ hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, 
 }
 
 static int g_scan_typed = 1;
+static int g_scan_long = [] {  // chunks of more than 1024 rows (AMG_HIP_SCAN_LONG=0: the round-2 walk)
+  const char* e = std::getenv("AMG_HIP_SCAN_LONG");
+  return (e && *e == '0') ? 0 : 1;
+}();
+bool gs_scan_long_chunks_ok(const DictRef& D) { return g_scan_long && D.rtype && g_scan_typed && D.scan_new <= 4; }
 void set_scan_typed(int on) { g_scan_typed = on ? 1 : 0; }
 // --------------------------------------------------------------- K-GS-scan ---
 // Lexicographic Gauss-Seidel at size (smoother.hpp:148-174).  On the reference's Galerkin
@@ -3027,23 +3032,41 @@ __global__ __launch_bounds__(1024) void gs_scan_typed_kernel(
     }
     return;
   }
+  uint32_t cty = 0xFFFFFFFFu;  // row type whose weights the lane holds
+  double cwv[SCAN_NEW], cqv = 0.0;
+  int32_t cof[SCAN_NEW];
+#pragma unroll
+  for (int e = 0; e < SCAN_NEW; ++e) {
+    cwv[e] = 0.0;
+    cof[e] = 0;
+  }
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     double Q = 1.0, Cc = 0.0;
     if (active) {
       fetch(chunk + 2, nx2);  // in flight during two scans
       double q = 0.0, c = 0.0;
-      if (cur.live) {
+      // the weights of the lane's row type stay in registers from chunk to chunk: a lane walks
+      // down one grid column, whose rows share a type except at the first and last lines, so the
+      // nine table reads per row (of thirteen LDS reads) are skipped while no lane of the wave
+      // changes type -- one workgroup's LDS instruction rate is what bounds this kernel
+      if (__builtin_amdgcn_ballot_w64(cur.ty != cty) != 0) {
         const int tb = (int)cur.ty * SCAN_NEW;
-        double rv[SCAN_NEW], wv[SCAN_NEW];
 #pragma unroll
         for (int e = 0; e < SCAN_NEW; ++e) {
-          wv[e] = tw[tb + e];
-          rv[e] = ring[(cur.k + toff[tb + e]) & ringmask];
+          cwv[e] = tw[tb + e];
+          cof[e] = toff[tb + e];
         }
+        cqv = tq[cur.ty];
+        cty = cur.ty;
+      }
+      if (cur.live) {
+        double rv[SCAN_NEW];
+#pragma unroll
+        for (int e = 0; e < SCAN_NEW; ++e) rv[e] = ring[(cur.k + cof[e]) & ringmask];
         c = cur.p;
 #pragma unroll
-        for (int e = 0; e < SCAN_NEW; ++e) c -= wv[e] * rv[e];   // unused slots: weight 0
-        q = tq[cur.ty];
+        for (int e = 0; e < SCAN_NEW; ++e) c -= cwv[e] * rv[e];   // unused slots: weight 0
+        q = cqv;
       }
       Q = q;
       Cc = c;
@@ -3077,6 +3100,147 @@ __global__ __launch_bounds__(1024) void gs_scan_typed_kernel(
   }
 }
 
+// The same walk with R = 2 or 4 CONSECUTIVE rows per thread, for chunks of more than 1024 rows (grid
+// lines of 2048 / 4096 and more: the finest levels of the big grids).  A chunk may be as long as
+// the distance to the previous grid line, and the serial walk pays per CHUNK (three barriers, two
+// scan levels), so a 4096-wide level takes a quarter of the chunks.  A thread folds its R affine
+// maps into one, the wave and workgroup scans run on the folded maps as before, and the thread
+// then walks its rows from the value before its block (the exclusive prefix: the inclusive result
+// of the lane below, through one cross-lane shift).  Same recurrence; the association of the
+// products differs from the one-row kernel (as that one's differs from the sequential sweep):
+// 1e-13 class.
+template <int WORDS, int UN, int R>
+__global__ __launch_bounds__(1024) void gs_scan_typed_rows_kernel(
+    int n, const uint8_t* __restrict__ rtype, const uint64_t* __restrict__ rwords,
+    const int32_t* __restrict__ doff, const double* __restrict__ dval, int ntab, double* u,
+    const double* __restrict__ P, int backward, int mode, double omega, int C, int ringmask) {
+  extern __shared__ double ring[];
+  __shared__ ScanEntry tab[256];
+  __shared__ uint64_t wtab[256 * WORDS];
+  __shared__ double tq[256];
+  __shared__ double tw[256 * SCAN_NEW];
+  __shared__ int32_t toff[256 * SCAN_NEW];
+  __shared__ double totQ[16], totC[16], carry_in[16];
+  __shared__ double last_u;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  scan_stage_tables(tab, wtab, WORDS, rtype, rwords, doff, dval, ntab);
+  for (int i = t; i <= ringmask; i += (int)blockDim.x) ring[i] = 0.0;
+  if (t == 0) last_u = 0.0;
+  __syncthreads();
+  scan_build_types<WORDS, UN>(tq, tw, toff, tab, wtab, backward, mode, omega);
+  __syncthreads();
+  const int nchunks = (n + C - 1) / C;
+  struct Row {
+    double p;
+    uint32_t ty;
+    int k;
+    bool live;
+  };
+  auto fetch = [&](int chunk, Row (&rw)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int j = t * R + r;
+      const int idx = chunk * C + j;
+      rw[r].live = chunk < nchunks && j < C && idx < n;
+      rw[r].k = backward ? n - 1 - idx : idx;
+      rw[r].ty = 255;
+      rw[r].p = 0.0;
+      if (rw[r].live) {
+        rw[r].ty = rtype[rw[r].k];
+        rw[r].p = P[rw[r].k];
+      }
+    }
+  };
+  const int nwaves = ((C + R - 1) / R + 63) >> 6;
+  const bool active = wave < nwaves;
+  Row cur[R], nx1[R], nx2[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) cur[r].live = nx1[r].live = nx2[r].live = false;
+  if (active) {
+    fetch(0, cur);
+    fetch(1, nx1);
+  }
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    double q[R], c[R];
+    double Q = 1.0, Cc = 0.0;
+    if (active) {
+      fetch(chunk + 2, nx2);  // in flight during two scans
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        q[r] = 0.0;
+        c[r] = 0.0;
+        // (the one-row kernel keeps the weights of a lane's row type in registers from chunk to
+        // chunk; with R rows per lane that costs more registers than it saves LDS reads: 4096^2
+        // 221 -> 241 ms per cycle, not kept here)
+        if (cur[r].live) {
+          const int tb = (int)cur[r].ty * SCAN_NEW;
+          double rv[SCAN_NEW], wv[SCAN_NEW];
+#pragma unroll
+          for (int e = 0; e < SCAN_NEW; ++e) {
+            wv[e] = tw[tb + e];
+            rv[e] = ring[(cur[r].k + toff[tb + e]) & ringmask];
+          }
+          double cc = cur[r].p;
+#pragma unroll
+          for (int e = 0; e < SCAN_NEW; ++e) cc -= wv[e] * rv[e];   // unused slots: weight 0
+          c[r] = cc;
+          q[r] = tq[cur[r].ty];
+        }
+      }
+      // the thread's R maps folded into one: (q_r, c_r) o (Q, Cc) = (q_r Q, c_r + q_r Cc)
+      Q = q[0];
+      Cc = c[0];
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        Cc = c[r] + q[r] * Cc;
+        Q = q[r] * Q;
+      }
+      affine_scan_wave(Q, Cc);
+      if (lane == 63) {
+        totQ[wave] = Q;
+        totC[wave] = Cc;
+      }
+    }
+    lds_barrier();
+    if (wave == 0) {
+      double sq = lane < nwaves ? totQ[lane & 15] : 1.0, sc = lane < nwaves ? totC[lane & 15] : 0.0;
+      affine_scan_wave(sq, sc);
+      const double after = sc + sq * last_u;
+      if (lane < 15) carry_in[lane + 1] = after;
+      if (lane == 0) carry_in[0] = last_u;
+    }
+    lds_barrier();
+    if (active) {
+      // value before this thread's block: the inclusive result of the lane below applied to the
+      // wave's carry (lane 0: the carry itself)
+      double Qp = __shfl_up(Q, 1), Cp = __shfl_up(Cc, 1);
+      if (lane == 0) {
+        Qp = 1.0;
+        Cp = 0.0;
+      }
+      double v = Cp + Qp * carry_in[wave];
+      const int len = (chunk * C + C <= n ? C : n - chunk * C);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        v = c[r] + q[r] * v;
+        if (cur[r].live) {
+          ring[cur[r].k & ringmask] = v;
+          u[cur[r].k] = v;
+        }
+        if (t * R + r == len - 1) last_u = v;
+      }
+    }
+    lds_barrier();                             // ring and last_u are ready for the next chunk
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      cur[r] = nx1[r];
+      nx1[r] = nx2[r];
+    }
+  }
+}
+constexpr int GS_SCAN_MAX_CHUNK = 4096;
+int gs_scan_max_chunk() { return GS_SCAN_MAX_CHUNK; }
+
 template <int WORDS, int UN>
 static hipError_t launch_gs_scan_wu(int64_t n, const DictRef& D, const double* b, double* u,
                                     double* s_old, int backward, int mode, double omega, int C,
@@ -3097,6 +3261,25 @@ static hipError_t launch_gs_scan_wu(int64_t n, const DictRef& D, const double* b
     hipLaunchKernelGGL((gs_scan_prep_typed_kernel<WORDS, UN>), dim3((unsigned)((n + 255) / 256)), dim3(256),
                        0, st, (int)n, D.rtype, D.rwords, D.doff, D.dval, D.ntab, b, u, backward, mode, omega,
                        s_old);
+    if (C > 1024) {  // long grid lines: 2 or 4 consecutive rows per thread
+      static bool attr3 = false;
+      if (!attr3) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gs_scan_typed_rows_kernel<WORDS, UN, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gs_scan_typed_rows_kernel<WORDS, UN, 4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        attr3 = true;
+      }
+      if (C <= 2048)
+        hipLaunchKernelGGL((gs_scan_typed_rows_kernel<WORDS, UN, 2>), dim3(1), dim3(1024), (size_t)ring * 8, st,
+                           (int)n, D.rtype, D.rwords, D.doff, D.dval, D.ntab, u, s_old, backward, mode, omega, C,
+                           ring - 1);
+      else
+        hipLaunchKernelGGL((gs_scan_typed_rows_kernel<WORDS, UN, 4>), dim3(1), dim3(1024), (size_t)ring * 8, st,
+                           (int)n, D.rtype, D.rwords, D.doff, D.dval, D.ntab, u, s_old, backward, mode, omega, C,
+                           ring - 1);
+      return hipGetLastError();
+    }
     // as many waves as the chunk has rows (at least the four that stage the tables): the three
     // barriers per chunk cost what the waves they hold up cost, and a deep level's chunk is short
     const int nt = std::max(256, (C + 63) / 64 * 64);
@@ -3105,6 +3288,7 @@ static hipError_t launch_gs_scan_wu(int64_t n, const DictRef& D, const double* b
                        ring - 1);
     return hipGetLastError();
   }
+  if (C > 1024) return hipErrorInvalidValue;  // only the row-typed form walks long chunks
   hipLaunchKernelGGL((gs_scan_prep_kernel<WORDS, UN>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                      (int)n, D.codes, D.rtype, D.rwords, D.doff, D.dval, D.ntab, u, backward, s_old);
   const int nt = std::max(256, (C + 63) / 64 * 64);
@@ -3113,12 +3297,13 @@ static hipError_t launch_gs_scan_wu(int64_t n, const DictRef& D, const double* b
                      omega, C, ring - 1);
   return hipGetLastError();
 }
-// C: rows per chunk (<= 1024 and <= the distance of the nearest non-chain dependency);
+// C: rows per chunk (<= the distance of the nearest non-chain dependency; <= 1024, or <= 4096 on a
+// row-typed matrix with at most SCAN_NEW new-side entries per row: gs_scan_long_chunks_ok);
 // ring: power of two >= largest dependency distance + C + 1, at most 16384 doubles
 hipError_t launch_gs_scan(int64_t n, const DictRef& D, const double* b, double* u, double* s_old,
                           bool backward, int mode, double omega, int C, int ring, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  if (!dict_args_ok(n, D.words, D.wmax, D.ntab) || C < 1 || C > 1024 || ring < 2 || ring > 16384 ||
+  if (!dict_args_ok(n, D.words, D.wmax, D.ntab) || C < 1 || C > GS_SCAN_MAX_CHUNK || ring < 2 || ring > 16384 ||
       (ring & (ring - 1)) || !s_old)
     return hipErrorInvalidValue;
   hipError_t r = hipSuccess;

@@ -285,6 +285,10 @@ hipError_t launch_gs_lex(const LexDev& S, const double* b, double* u, int mode, 
 void set_scan_typed(int on);  // K-GS-scan: per-type fast path on row-typed matrices (default on)
 // s_old: scratch of n doubles (the sums over rows the sweep has not reached, formed by a
 // parallel pre-pass).
+// chunks of up to gs_scan_max_chunk() rows (else 1024): row-typed matrices whose rows have at most 4
+// new-side entries besides the chain
+bool gs_scan_long_chunks_ok(const DictRef& D);
+int gs_scan_max_chunk();
 hipError_t launch_gs_scan(int64_t n, const DictRef& D, const double* b, double* u, double* s_old,
                           bool backward, int mode, double omega, int C, int ring, hipStream_t st);
 

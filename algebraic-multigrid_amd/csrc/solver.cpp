@@ -1841,7 +1841,8 @@ amg_hip_status build_solver(int64_t n, const int32_t* colptr, const int32_t* row
       const DevMat& A = L.A_rows;
       if (A.dict && A.dict_shift == 0 && A.scan_gap >= GS_SCAN_MIN_GAP) {
         int ring = 128;
-        const int C = (int)std::min<int64_t>(A.scan_gap, 1024);
+        int C = (int)std::min<int64_t>(A.scan_gap, gs_scan_long_chunks_ok(A.dict_ref()) ? gs_scan_max_chunk() : 1024);
+        if (C > 1024 && A.scan_far + C + 1 > 16384) C = 1024;  // the ring of new values must fit the LDS
         while (ring < A.scan_far + C + 1 && ring <= 16384) ring *= 2;
         if (ring <= 16384) {
           L.scan_C = C;
@@ -2329,7 +2330,8 @@ amg_hip_status build_poisson_device(int dim, int64_t n, int32_t n_levels, const 
     if (lex && (l + 1 < n_levels || o.keep_residual)) {  // K-GS-scan on every smoothed level, or the host path
       const DevMat& A = L.A_rows;
       int ring = 128;
-      const int C = (int)std::min<int64_t>(A.scan_gap, 1024);
+      int C = (int)std::min<int64_t>(A.scan_gap, gs_scan_long_chunks_ok(A.dict_ref()) ? gs_scan_max_chunk() : 1024);
+      if (C > 1024 && A.scan_far + C + 1 > 16384) C = 1024;  // the ring of new values must fit the LDS
       while (ring < A.scan_far + C + 1 && ring <= 16384) ring *= 2;
       if (A.scan_gap < GS_SCAN_MIN_GAP || ring > 16384) return AMG_HIP_OK;
       L.scan_C = C;

@@ -119,3 +119,24 @@ def test_3d_stencil_rows_paired_loads_are_bit_neutral(amg):
     for l in range(L - 1):
         assert np.array_equal(out[0][1][l], out[1][1][l]), l + 1
     assert out[0][2] == out[1][2]
+
+
+@pytest.mark.parametrize("n,L,kind", [(2048, 5, "spgs"), (3001, 8, "spgs"), (2050, 6, "sor")])
+def test_scan_long_chunks_against_the_oracle(amg, oracle, n, L, kind):
+    """K-GS-scan with chunks of more than 1024 rows (grid lines of 2048 / 4096+: 2 or 4 consecutive rows
+    per thread, gs_scan_typed_rows_kernel) -- the reference's own sweeps (smoother.hpp:148-174,
+    :339-372) against the sequential oracle: 1e-10 on every level after 2 cycles, incl. ragged line
+    ends (n odd) and lines that are not a multiple of the rows per thread."""
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    kw_o = dict(smoother=oracle.SM_SOR, smoother_iters=1, omega=1.3) if kind == "sor" else dict(smoother=oracle.SM_SPGS)
+    kw_g = dict(smoother=amg.SM_SOR, smoother_iters=1, omega=1.3) if kind == "sor" else dict(smoother=amg.SM_SPGS)
+    ref = oracle.Multigrid(A, b, L, **kw_o)
+    mg = amg.Multigrid(*csc(A), b, L, **kw_g)
+    for c in range(2):
+        ref.vcycle()
+        mg.vcycle()
+    for l in range(L):
+        ur = ref.get_vec(l, "u")
+        assert np.linalg.norm(mg.get_soln(l) - ur) <= 1e-10 * np.linalg.norm(ur), (kind, l)
+    assert abs(mg.rss() - ref.rss()) <= 1e-10 * ref.rss()
+    mg.close()
