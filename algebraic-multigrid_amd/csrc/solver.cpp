@@ -672,9 +672,15 @@ struct CoarseOnDev {
 };
 // level-0 rows from which the lexicographic smoothers take the line-scan form by default
 constexpr int64_t GS_SCAN_MIN_ROWS = 65536;
-// ... and the shortest chunk worth it: a chunk costs ~1 us whatever its length, a serial row of
-// the exact kernel ~0.33 us, so below 4 rows per chunk the exact kernel is as fast
-constexpr int64_t GS_SCAN_MIN_GAP = 4;
+// ... and the shortest chunk worth it.  A chunk of at most 64 rows is one wave's scan without a
+// barrier (~0.3 us), a serial row of the exact kernel costs ~0.33 us: from two rows per chunk on the
+// scan form wins (round 3: 4 -> 2; 4096^2 / 16 levels 217 -> 198 ms per cycle, 1024^2 / 12 levels
+// 30.4 -> 26.1 ms, and a hierarchy without exact-kernel levels is set up on the device: 2.75 ->
+// 0.48 s).  AMG_HIP_SCAN_MIN_GAP overrides.
+static const int64_t GS_SCAN_MIN_GAP = [] {
+  const char* e = std::getenv("AMG_HIP_SCAN_MIN_GAP");
+  return e ? (int64_t)std::atoi(e) : (int64_t)2;
+}();
 // serial substitution costs ~44 ns per row and pass; from this size on the partitioned
 // solve is the default (opt.exact_coarse_solve keeps the bit-exact one)
 constexpr int64_t COARSE_SPIKE_MIN_ROWS = 4096;

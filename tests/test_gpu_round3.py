@@ -140,3 +140,24 @@ def test_scan_long_chunks_against_the_oracle(amg, oracle, n, L, kind):
         assert np.linalg.norm(mg.get_soln(l) - ur) <= 1e-10 * np.linalg.norm(ur), (kind, l)
     assert abs(mg.rss() - ref.rss()) <= 1e-10 * ref.rss()
     mg.close()
+
+
+@pytest.mark.parametrize("n,L", [(1024, 12), (600, 10)])
+def test_scan_on_the_deep_levels_against_the_oracle(amg, oracle, n, L):
+    """The reference's SparseGaussSeidel() on a deep hierarchy: the levels whose grid lines are down
+    to 4 / 2 / 1 columns (chunks of 3 and 2 rows, one wave each) take K-GS-scan too since round 3
+    (they were the exact kernel's) -- 1e-10 against the sequential oracle on every level after 2
+    cycles, through both constructors (device-only setup and host arrays)."""
+    A, b = oracle.laplacian(n), oracle.rhs(n)
+    ref = oracle.Multigrid(A, b, L)
+    mgs = [amg.Multigrid(*csc(A), b, L), amg.Multigrid.poisson(n, L)]
+    for _ in range(2):
+        ref.vcycle()
+        for mg in mgs:
+            mg.vcycle()
+    for mg in mgs:
+        for l in range(L):
+            ur = ref.get_vec(l, "u")
+            assert np.linalg.norm(mg.get_soln(l) - ur) <= 1e-10 * np.linalg.norm(ur), l
+        assert abs(mg.rss() - ref.rss()) <= 1e-10 * ref.rss()
+        mg.close()
