@@ -2091,6 +2091,216 @@ hipError_t launch_dict_pair_up(int64_t n, const DictRef& D, int hb, const double
                        a, f, u_out, omega, hbw, (int)n_h, uh_in, uh_out, dict_xcd_map(D));
   });
 }
+// ---- K-March: two true-Jacobi sweeps of a 3-D 7-point level in ONE pass ---------------------
+// On the finest level of a 3-D hierarchy a sweep streams x, f and the output again (25 B per row),
+// and the +-plane neighbours defeat the 2-D patch form (three rings around planes x lines x columns
+// leave a quarter of a patch as output).  Here a workgroup owns a tile of TL lines x TC columns and
+// MARCHES through the planes: x of plane q arrives (tile + 2 rings in the plane), the first sweep is
+// formed on plane q-1 (tile + 1 ring) from the x planes q-2, q-1, q, the second sweep on plane q-2
+// (tile) from the first-sweep planes q-3, q-2, q-1 -- two rings of three planes in LDS, two barriers
+// per plane, only the two in-plane directions pay a halo.  Row structure from the row TYPE: the
+// values of every type laid out by pattern position {-M, -m, -1, (0), +1, +m, +M} by the host
+// (positions a boundary row does not have: +0.0, its diagonal apart); waves of interior cells take
+// the interior type's values from kernel arguments.  Same products in the same (ascending column)
+// order, the same IEEE division and relaxation expression as dict_rows<CSR_JACOBI>, adding (+0.0) x
+// where dict_rows adds it for absent slots -> same bits as two launches of the sweep.
+constexpr int MARCH_TL = 16, MARCH_TC = 64, MARCH_NT = 512;  // (8 lines x 256 threads: 0.8 % slower)
+constexpr int MARCH_XL = MARCH_TL + 4, MARCH_XC = MARCH_TC + 4;  // x tile: 20 x 68
+constexpr int MARCH_SL = MARCH_TL + 2, MARCH_SC = MARCH_TC + 2;  // first-sweep tile: 18 x 66
+constexpr int MARCH_XN = MARCH_XL * MARCH_XC, MARCH_SN = MARCH_SL * MARCH_SC;
+constexpr int MARCH_XS = (MARCH_XN + MARCH_NT - 1) / MARCH_NT;   // x cells per thread (3)
+constexpr int MARCH_SS = (MARCH_SN + MARCH_NT - 1) / MARCH_NT;   // first-sweep cells per thread (3)
+constexpr int MARCH_OS = MARCH_TL * MARCH_TC / MARCH_NT;         // output cells per thread (2)
+constexpr int MARCH_TYPES = 64;
+typedef MarchRef MarchArgs;
+// one Jacobi update of a cell from its six neighbours nb[] (-M, -m, -1, +1, +m, +M) and itself
+__device__ __forceinline__ double march_update(const double (&w)[6], double diag, const double (&nb)[6],
+                                               double xi, double fi, double omega) {
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < 6; ++u) acc += w[u] * nb[u];
+  const bool nod = diag == 0.0;
+  const double q = (fi - acc) / (nod ? 1.0 : diag);  // smoother.hpp:136
+  return nod ? xi : xi + omega * (q - xi);
+}
+__global__ __launch_bounds__(MARCH_NT) void march_kernel(MarchArgs A) {
+  __shared__ double X[3][MARCH_XN];
+  __shared__ double S[3][MARCH_SN];
+  __shared__ double wt[MARCH_TYPES * 8];  // per type: w[6] (pattern order without the diagonal), diagonal, -
+  const int tid = (int)threadIdx.x;
+  const int tiles_c = A.m / MARCH_TC, tiles_l = A.lines / MARCH_TL;
+  const int tile = (int)blockIdx.x % (tiles_c * tiles_l), chunk = (int)blockIdx.x / (tiles_c * tiles_l);
+  const int l0 = (tile / tiles_c) * MARCH_TL, c0 = (tile % tiles_c) * MARCH_TC;
+  const int pa = chunk * A.chunk_planes, pb = min(pa + A.chunk_planes, A.planes);
+  for (int q = tid; q < A.ntypes * 8; q += MARCH_NT) wt[q] = A.wtab[q];
+  // cells of this thread
+  int xoff[MARCH_XS];   // global row offset inside a plane (line * m + col), or -1 outside the domain
+#pragma unroll
+  for (int k = 0; k < MARCH_XS; ++k) {
+    const int q = k * MARCH_NT + tid;
+    const int line = l0 - 2 + q / MARCH_XC, col = c0 - 2 + q % MARCH_XC;
+    xoff[k] = (q < MARCH_XN && line >= 0 && line < A.lines && col >= 0 && col < A.m) ? line * A.m + col : -1;
+  }
+  // first-sweep cells of this thread: its two OUTPUT cells (so that their f and row type are still in
+  // registers when the second sweep reaches the plane, one step later) and one cell of the ring
+  // around the tile (164 cells: the first 164 threads).  soff: row offset in the plane or -1, si / sx:
+  // index in the first-sweep tile / in the x tile.
+  static_assert(MARCH_SS == MARCH_OS + 1 && 2 * MARCH_SC + 2 * MARCH_TL <= MARCH_NT, "first-sweep cell map");
+  int soff[MARCH_SS], si[MARCH_SS], sx[MARCH_SS];
+  int ooff[MARCH_OS];
+#pragma unroll
+  for (int k = 0; k < MARCH_OS; ++k) {
+    const int q = k * MARCH_NT + tid;
+    const int ol = q / MARCH_TC, oc = q % MARCH_TC;
+    ooff[k] = (l0 + ol) * A.m + c0 + oc;   // always inside the domain
+    soff[k] = ooff[k];
+    si[k] = (ol + 1) * MARCH_SC + oc + 1;
+    sx[k] = (ol + 2) * MARCH_XC + oc + 2;
+  }
+  {
+    const int r = tid;
+    int sl, sc;
+    if (r < MARCH_SC) { sl = 0; sc = r; }
+    else if (r < 2 * MARCH_SC) { sl = MARCH_SL - 1; sc = r - MARCH_SC; }
+    else if (r < 2 * MARCH_SC + MARCH_TL) { sl = r - 2 * MARCH_SC + 1; sc = 0; }
+    else { sl = r - 2 * MARCH_SC - MARCH_TL + 1; sc = MARCH_SC - 1; }
+    const bool ring = r < 2 * MARCH_SC + 2 * MARCH_TL;
+    if (!ring) { sl = 1; sc = 1; }
+    const int line = l0 - 1 + sl, col = c0 - 1 + sc;
+    soff[MARCH_OS] = (ring && line >= 0 && line < A.lines && col >= 0 && col < A.m) ? line * A.m + col : -1;
+    si[MARCH_OS] = ring ? sl * MARCH_SC + sc : -1;   // -1: no cell (nothing is stored)
+    sx[MARCH_OS] = (sl + 1) * MARCH_XC + sc + 1;
+  }
+  const int64_t M = (int64_t)A.m * A.lines;
+  double xr[MARCH_XS];  // x of the plane that arrives next
+  auto fetch_x = [&](int plane) {
+#pragma unroll
+    for (int k = 0; k < MARCH_XS; ++k)
+      xr[k] = (plane >= 0 && plane < A.planes && xoff[k] >= 0) ? A.x[(int64_t)plane * M + xoff[k]] : 0.0;
+  };
+  double wi[6];
+#pragma unroll
+  for (int u = 0; u < 6; ++u) wi[u] = A.wint[u];
+  const double di = A.dint;
+  const uint32_t ti = (uint32_t)A.tint;
+  // operands (f, row type) of the first sweep on plane q - 1 and of the second on plane q - 2:
+  // requested one plane step ahead, like x (a step is two barriers and a few dozen LDS reads; a
+  // global round trip inside it would be most of its time)
+  double nf1[MARCH_SS];
+  uint32_t nt1[MARCH_SS];
+  auto fetch_ops = [&](int q) {
+    const int p1 = q - 1;
+    const bool live1 = p1 >= pa - 1 && p1 <= pb && p1 >= 0 && p1 < A.planes;
+#pragma unroll
+    for (int k = 0; k < MARCH_SS; ++k) {
+      const bool live = live1 && soff[k] >= 0;
+      const int64_t r = live ? (int64_t)p1 * M + soff[k] : 0;
+      nf1[k] = live ? A.f[r] : 0.0;
+      nt1[k] = live ? (uint32_t)A.rtype[r] : 255u;
+    }
+  };
+  double f2[MARCH_OS];   // operands of the second sweep: what the first sweep used one step ago
+  uint32_t t2[MARCH_OS];
+#pragma unroll
+  for (int k = 0; k < MARCH_OS; ++k) {
+    f2[k] = 0.0;
+    t2[k] = 255u;
+  }
+  fetch_x(pa - 2);
+  fetch_ops(pa - 2);
+  __syncthreads();
+  for (int q = pa - 2; q <= pb + 1; ++q) {
+    // x of plane q into its ring slot; the next plane is requested
+    {
+      double* Xq = X[(q + 3) % 3];
+#pragma unroll
+      for (int k = 0; k < MARCH_XS; ++k)
+        if (k * MARCH_NT + tid < MARCH_XN) Xq[k * MARCH_NT + tid] = xr[k];
+    }
+    const int p1 = q - 1, p2 = q - 2;
+    const bool do1 = p1 >= pa - 1 && p1 <= pb;
+    const bool do2 = p2 >= pa && p2 < pb;
+    double f1[MARCH_SS];
+    uint32_t t1[MARCH_SS];
+#pragma unroll
+    for (int k = 0; k < MARCH_SS; ++k) {
+      f1[k] = nf1[k];
+      t1[k] = nt1[k];
+    }
+    fetch_x(q + 1);
+    fetch_ops(q + 1);
+    lds_barrier();
+    if (do1) {  // first sweep on plane q - 1 from the x planes q - 2, q - 1, q
+      const double* Xm = X[(q + 1) % 3];  // plane q - 2
+      const double* Xc = X[(q + 2) % 3];  // plane q - 1
+      const double* Xp = X[(q + 3) % 3];  // plane q
+      double* Sq = S[(p1 + 3) % 3];
+#pragma unroll
+      for (int k = 0; k < MARCH_SS; ++k) {
+        const int i = sx[k];
+        const double nb[6] = {Xm[i], Xc[i - MARCH_XC], Xc[i - 1], Xc[i + 1], Xc[i + MARCH_XC], Xp[i]};
+        const double xi = Xc[i];
+        const bool live = t1[k] != 255u;
+        double r;
+        if (__builtin_amdgcn_ballot_w64(live && t1[k] != ti) == 0) {  // interior (or dead) cells only
+          r = march_update(wi, di, nb, xi, f1[k], A.omega);
+        } else {
+          const uint32_t tt = t1[k] < (uint32_t)MARCH_TYPES ? t1[k] : 0u;
+          double w[6];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) w[u] = wt[tt * 8 + u];
+          r = march_update(w, wt[tt * 8 + 6], nb, xi, f1[k], A.omega);
+        }
+        if (si[k] >= 0) Sq[si[k]] = live ? r : 0.0;
+      }
+    }
+    lds_barrier();
+    if (do2) {  // second sweep on plane q - 2 from the first-sweep planes q - 3, q - 2, q - 1
+      const double* Sm = S[(p2 + 2) % 3];
+      const double* Sc = S[(p2 + 3) % 3];
+      const double* Sp = S[(p2 + 4) % 3];
+#pragma unroll
+      for (int k = 0; k < MARCH_OS; ++k) {
+        const int i = si[k];
+        const double nb[6] = {Sm[i], Sc[i - MARCH_SC], Sc[i - 1], Sc[i + 1], Sc[i + MARCH_SC], Sp[i]};
+        const double xi = Sc[i];
+        double r;
+        if (__builtin_amdgcn_ballot_w64(t2[k] != ti) == 0) {
+          r = march_update(wi, di, nb, xi, f2[k], A.omega);
+        } else {
+          const uint32_t tt = t2[k] < (uint32_t)MARCH_TYPES ? t2[k] : 0u;
+          double w[6];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) w[u] = wt[tt * 8 + u];
+          r = march_update(w, wt[tt * 8 + 6], nb, xi, f2[k], A.omega);
+        }
+        A.out[(int64_t)p2 * M + ooff[k]] = r;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MARCH_OS; ++k) {  // plane q - 1 is the second sweep's plane of the next step
+      f2[k] = f1[k];
+      t2[k] = t1[k];
+    }
+  }
+}
+bool march_ok(const MarchRef& A) {
+  return A.m >= MARCH_TC && A.m % MARCH_TC == 0 && A.lines >= MARCH_TL && A.lines % MARCH_TL == 0 && A.planes >= 3 &&
+         (int64_t)A.m * A.lines * A.planes < ((int64_t)1 << 31) - 1024 && A.ntypes >= 1 && A.ntypes <= MARCH_TYPES &&
+         A.tint >= 0 && A.tint < A.ntypes && A.chunk_planes >= 1 && A.wtab && A.rtype && A.x && A.f && A.out &&
+         A.out != A.x;
+}
+hipError_t launch_march(MarchRef A, hipStream_t st) {
+  // one wave of workgroups (2 per CU x 256 CUs): as many plane chunks as that takes
+  const int64_t tiles = (int64_t)(A.m / MARCH_TC) * (A.lines / MARCH_TL);
+  int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(A.planes / 8, (512 + tiles - 1) / tiles));
+  A.chunk_planes = (A.planes + chunks - 1) / chunks;
+  chunks = (A.planes + A.chunk_planes - 1) / A.chunk_planes;
+  if (!march_ok(A)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(march_kernel, dim3((unsigned)(tiles * chunks)), dim3(MARCH_NT), 0, st, A);
+  return hipGetLastError();
+}
+
 // ---- K-Strip: the multicolour smoother's whole leg of a NARROW level in one launch ----------
 // Below the K-Patch levels (pitch < 128) the symmetric pass of a 4-colour level is 7 colour
 // launches of ~5 us each with almost nothing to do, plus the residual + restriction or the

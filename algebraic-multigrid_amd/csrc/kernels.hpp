@@ -179,6 +179,22 @@ hipError_t launch_patch_rb(bool prolong, bool tail, int64_t n, int64_t m, const 
                            const double* f, const double* uH, int64_t nH, double* u_out, double* r_out,
                            double* fH, double* uH_zero, uint32_t stages, uint32_t ctab, hipStream_t st,
                            int64_t line_lo = 0, int64_t line_hi = -1);
+// K-March (kernels.hip): two true-Jacobi sweeps x -> out of a 3-D 7-point level (rows = plane * m *
+// lines + line * m + column) in one plane-marching pass.  wtab: per row type 8 doubles {w(-M), w(-m),
+// w(-1), w(+1), w(+m), w(+M), diagonal, 0} (+0.0 where the type has no entry); tint / wint / dint: the
+// interior type and its values.  out != x.
+struct MarchRef {
+  int m = 0, lines = 0, planes = 0, ntypes = 0, tint = -1, chunk_planes = 0;
+  double omega = 1.0, dint = 0.0;
+  double wint[6] = {0, 0, 0, 0, 0, 0};
+  const double* wtab = nullptr;
+  const uint8_t* rtype = nullptr;
+  const double* x = nullptr;
+  const double* f = nullptr;
+  double* out = nullptr;
+};
+bool march_ok(const MarchRef& A);
+hipError_t launch_march(MarchRef A, hipStream_t st);
 // K-Strip (kernels.hip): the colour stages of a narrow level's whole leg in one launch over strips
 // of T rows (+ halo), any colouring (colour byte per row, < 16 colours); stages: 4 bits per stage.
 // prolong: the input is x + P uH; tail: followed by the residual (r_out optional), the restriction

@@ -258,6 +258,11 @@ struct DevMat {
   bool dict_typed = false;    // second level: one byte per row into a table of code words
   DevMem dcodes, doff, dval, drtype, drwords;
   DevMem dutd, duti;  // per row type: values / diagonal, offsets + slot mask + stencil pattern (DictRef::utd, uti)
+  // K-March (3-D 7-point level: every row type's columns within {-M, -m, -1, 0, 1, m, M}): per type
+  // {w(-M), w(-m), w(-1), w(+1), w(+m), w(+M), diagonal, 0}; the interior type and its values
+  DevMem dmarch;
+  int march_m = 0, march_M = 0, march_ntypes = 0, march_tint = -1;
+  double march_wint[6] = {0, 0, 0, 0, 0, 0}, march_dint = 0.0;
   // K-GS-scan: nearest dependency of a lexicographic sweep other than the chained neighbour
   // (min |offset| over the pairs with |offset| >= 2) and the farthest one; 0 = not usable
   int64_t scan_gap = 0, scan_far = 0;
@@ -478,6 +483,59 @@ hipError_t finish_dict(const DictMat& T, int64_t n, int64_t diag_shift, DevMat* 
         mx = std::max(mx, std::max(lo, hi));
       }
       D->scan_new = mx;
+    }
+  }
+  D->march_ntypes = 0;
+  if (D->dict_typed && diag_shift == 0 && T.rwords.size() >= (size_t)256 * T.words && T.words <= 2) {
+    // K-March table: find the interior 7-point type, then lay every type out by pattern position
+    int64_t pm = 0, pM = 0;
+    int tint = -1;
+    std::vector<std::vector<std::pair<int64_t, double>>> rows(255);
+    int last = -1;
+    for (int t = 0; t < 255; ++t) {
+      for (int sl = 0; sl < 8 * T.words; ++sl) {
+        const int code = (int)((T.rwords[(size_t)t * T.words + sl / 8] >> (8 * (sl % 8))) & 0xFF);
+        if (code == 0xFF || code >= (int)T.doff.size()) continue;
+        rows[(size_t)t].push_back({(int64_t)T.doff[(size_t)code], T.dval[(size_t)code]});
+      }
+      const auto& r = rows[(size_t)t];
+      if (!r.empty()) last = t;
+      if (tint < 0 && r.size() == 7 && r[2].first == -1 && r[3].first == 0 && r[4].first == 1 &&
+          r[5].first > 1 && r[6].first > r[5].first && r[1].first == -r[5].first && r[0].first == -r[6].first &&
+          r[6].first % r[5].first == 0) {
+        tint = t;
+        pm = r[5].first;
+        pM = r[6].first;
+      }
+    }
+    if (tint >= 0 && last < 64 && pM < ((int64_t)1 << 30) && n % pM == 0) {
+      const int64_t P[6] = {-pM, -pm, -1, 1, pm, pM};
+      std::vector<double> wt((size_t)(last + 1) * 8, 0.0);
+      bool ok = true;
+      for (int t = 0; t <= last && ok; ++t) {
+        double diag = 0.0;
+        for (const auto& e : rows[(size_t)t]) {
+          if (e.first == 0) {
+            diag = diag + e.second;
+            continue;
+          }
+          int at = -1;
+          for (int u = 0; u < 6; ++u)
+            if (P[u] == e.first) at = u;
+          if (at < 0) { ok = false; break; }
+          wt[(size_t)t * 8 + at] = e.second;
+        }
+        wt[(size_t)t * 8 + 6] = diag;
+      }
+      if (ok) {
+        if ((e = upload(D->dmarch, wt.data(), wt.size())) != hipSuccess) return e;
+        D->march_m = (int)pm;
+        D->march_M = (int)pM;
+        D->march_ntypes = last + 1;
+        D->march_tint = tint;
+        for (int u = 0; u < 6; ++u) D->march_wint[u] = wt[(size_t)tint * 8 + u];
+        D->march_dint = wt[(size_t)tint * 8 + 6];
+      }
     }
   }
   D->patch = false;
@@ -889,6 +947,11 @@ struct Slab {
 // amg_hip_set_tail_fusion / AMG_HIP_TAIL_FUSION=1: K-Tail (deepest levels + coarsest solve in one
 // launch).  Off by default: bit-identical, and measured 0.5 % SLOWER than one launch per step on the
 // 4096^2 cycle (1282 / 1291 / 1293 against 1299 / 1301 / 1294 V-cycles/s, alternating runs).
+// K-March on / off (AMG_HIP_MARCH=0: two launches of the sweep)
+int g_march = [] {
+  const char* e = std::getenv("AMG_HIP_MARCH");
+  return (e && *e == '0') ? 0 : 1;
+}();
 int g_tail_fusion = [] {
   const char* e = std::getenv("AMG_HIP_TAIL_FUSION");
   return (e && *e == '1') ? 1 : 0;
@@ -1106,6 +1169,32 @@ int tail_from(const amg_hip_solver* s) {
   return -1;
 }
 
+// K-March: the two plain Jacobi sweeps u -> tmp -> u of a 3-D 7-point level as ONE launch u -> tmp
+// (kernels.hip: march_kernel); the level's two vectors then trade places (a level is swept twice
+// per cycle this way -- down-leg and up-leg --, so every cycle ends with them where it found them).
+static bool march_fill(const amg_hip_solver* s, int l, MarchRef* R) {
+  const Level& L = s->lv[l];
+  const DevMat& A = L.A_cols();
+  if (!(s->opt.smoother == AMG_HIP_SM_JACOBI && s->opt.smoother_iters == 2 && !s->opt.no_fusion && !s->opt.window &&
+        s->slab.levels == 0 && A.dict && A.dict_typed && A.march_ntypes > 0 && A.dmarch.p && A.march_m > 0 &&
+        L.n % A.march_M == 0 && A.march_M % A.march_m == 0 && g_march))
+    return false;
+  R->m = A.march_m;
+  R->lines = A.march_M / A.march_m;
+  R->planes = (int)(L.n / A.march_M);
+  R->ntypes = A.march_ntypes;
+  R->tint = A.march_tint;
+  R->omega = s->opt.omega;
+  R->dint = A.march_dint;
+  for (int u = 0; u < 6; ++u) R->wint[u] = A.march_wint[u];
+  R->wtab = A.dmarch.as<double>();
+  R->rtype = A.drtype.as<uint8_t>();
+  R->f = L.f.as<double>();
+  R->x = L.u.as<double>();
+  R->out = L.tmp.as<double>();
+  R->chunk_planes = 1;
+  return march_ok(*R);
+}
 // phase 3: the first sweep was already done by the fused kernel of the finer level
 // (result in tmp).  prolong_into >= 0: the last sweep also adds P u_l to that level's u.
 amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolong_into = -1,
@@ -1169,6 +1258,17 @@ amg_hip_status enqueue_smooth(amg_hip_solver* s, int l, int phase = 0, int prolo
         s->acct(mat_bytes(A) + 24.0 * L.n + 8.0 * C.n);
         std::swap(a, b);
         it = 1;
+      }
+      if (it == 0 && prolong_into < 0) {
+        MarchRef R;
+        // (only inside a whole V-cycle, which sweeps the level twice: a lone smooth() must leave the
+        // vectors where a captured graph expects them)
+        if (s->acct_part == 0 /* CYCLE_ALL */ && march_fill(s, l, &R)) {  // both sweeps in one pass: u -> tmp, then trade
+          HIP_TRY(launch_march(R, st));
+          s->acct(mat_bytes(A) + 24.0 * L.n);
+          std::swap(L.u, L.tmp);
+          return AMG_HIP_OK;
+        }
       }
       for (; it < iters; ++it) {
         if (prolong_into >= 0 && it == iters - 1) {
@@ -3148,6 +3248,8 @@ amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
   // level's whole down-leg (2 sweeps + residual + restriction + first coarse sweep); it also
   // rewrites f and tmp of level 1, which every V-cycle recomputes before use.
   const bool patch = !mc && patch_level_ok(s, 0);
+  MarchRef MR;
+  const bool march = !mc && !patch && march_fill(s, 0, &MR);
   // slab-sharded solver: this rank's launch, i.e. its own lines + halo only
   const bool slab = patch && s->slab.levels > 0 && s->slab.world > 1;
   for (int i = 0; i < n_launches; ++i) {
@@ -3169,6 +3271,8 @@ amg_hip_status amg_hip_profile_fine_sweep(amg_hip_solver* s, int32_t n_launches,
                                      L.mc_mat.scol.as<int32_t>(), L.mc_mat.sval.as<double>(),
                                      L.mc_rowid.as<int32_t>(), L.mc_start[0], L.mc_start[1] - L.mc_start[0],
                                      L.f.as<double>(), L.u.as<double>(), s->stream));
+    } else if (march) {  // both sweeps of level 0 in one plane-marching pass: u -> tmp
+      HIP_TRY(launch_march(MR, s->stream));
     } else if (patch) {
       Level& C = s->lv[1];
       HIP_TRY(launch_patch_down(true, L.n, A.patch_m, A.patch_ref(), L.u.as<double>(),
@@ -3252,6 +3356,11 @@ amg_hip_status amg_hip_fine_sweep_info(const amg_hip_solver* s, char* name, int3
       const int64_t l1 = std::min<int64_t>(s->slab.lines, (s->slab.down_hi[0] + th - 1) / th * th);
       bytes *= (double)(l1 - l0) / (double)s->slab.lines;
     }
+  } else if (MarchRef MR; A.dict && march_fill(s, 0, &MR)) {
+    // both sweeps of the level in one pass: row types + x + f + out
+    std::snprintf(name, (size_t)name_cap, "march_kernel");
+    sweeps = 2;
+    bytes = (double)mat + 24.0 * (double)L.n;
   } else if (A.dict) {
     dict_kernel_name(CSR_JACOBI, A.n_rows, A.dict_ref(), L.f.p, L.tmp.p, name, (size_t)name_cap);
     bytes = (double)mat + 24.0 * (double)L.n;  // matrix stream (1 B / row) + f + x + out

@@ -248,8 +248,11 @@ def fine_sweep_roofline(amg, mg, args, lay_name, mat_bytes, n0, csr_formula_byte
       fraction.  The library reports the figure (amg_hip_fine_sweep_info)."""
     avg_ms, min_ms, sweeps_per_launch, kname, must_move = mg.profile_fine_sweep(launches or args.profile_launches)
     if kname.startswith("patch_rb"):
-        model = ("K-Patch form of the multicolour pass on the red-black level 0: one launch = two colour "
-                 "stages over the level: n*(1 B row type + x + f + out)")
+        model = ("K-Patch form of the multicolour pass on the red-black level 0: one launch = the first colour "
+                 "stage(s) of the level's down-leg: n*(1 B row type + x + f + out)")
+    elif kname.startswith("march_kernel"):
+        model = ("K-March: both Jacobi sweeps of the 3-D 7-point level 0 in one plane-marching launch: "
+                 "n*(1 B row type + x + f + out)")
     elif kname.startswith("dict_gs_color") or kname.startswith("sell_kernel<5"):
         model = "rows of colour 0: matrix stream of those rows (code words / panels + dof id) + f + u written"
     elif kname.startswith("patch_down"):

@@ -161,3 +161,30 @@ def test_scan_on_the_deep_levels_against_the_oracle(amg, oracle, n, L):
             assert np.linalg.norm(mg.get_soln(l) - ur) <= 1e-10 * np.linalg.norm(ur), l
         assert abs(mg.rss() - ref.rss()) <= 1e-10 * ref.rss()
         mg.close()
+
+
+@pytest.mark.parametrize("n,L", [(64, 9), (128, 11)])
+def test_march_two_sweeps_in_one_pass_3d(amg, oracle, n, L):
+    """K-March (round 3): the two plain Jacobi sweeps of the 3-D 7-point fine level as ONE plane-marching
+    launch (down-leg and up-leg; the level's two vectors trade places after each) against two
+    launches of the dictionary sweep (no_fusion) -- every level vector bitwise after 3 cycles --
+    and, at 64^3, against the oracle twin."""
+    kw = dict(smoother=amg.SM_JACOBI, smoother_iters=2, omega=0.6)
+    out = []
+    for nf in (False, True):
+        mg = amg.Multigrid.poisson(n, L, dim=3, no_fusion=nf, **kw)
+        mg.vcycle(3)
+        out.append(([mg.get_soln(l) for l in range(L)], [mg.get_rhs(l) for l in range(1, L)], mg.rss()))
+        if not nf and n == 64:
+            A, b = oracle.laplacian(n, dim=3), oracle.rhs(n, dim=3)
+            ref = oracle.Multigrid(A, b, L, smoother=oracle.SM_TRUE_JACOBI, smoother_iters=2, omega=0.6)
+            for _ in range(3):
+                ref.vcycle()
+            assert np.array_equal(out[0][0][0], ref.get_vec(0, "u"))
+            assert np.array_equal(out[0][0][1], ref.get_vec(1, "u"))
+        mg.close()
+    for l in range(L):
+        assert np.array_equal(out[0][0][l], out[1][0][l]), l
+    for l in range(L - 1):
+        assert np.array_equal(out[0][1][l], out[1][1][l]), l + 1
+    assert out[0][2] == out[1][2]
